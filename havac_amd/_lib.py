@@ -1,0 +1,66 @@
+"""ctypes binding of libhavac_dev.so (include/havac_dev.h).
+
+There is no fallback: if the HIP library has not been built, or cannot be
+loaded, importing the symbols raises.  Nothing in this package computes SSV on
+the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhavac_dev.so")
+
+HAVAC_OK = 0
+E_LENGTH, E_LOGIC, E_RUNTIME, E_NOMEM, E_HIT_OVERFLOW, E_NO_DEVICE, E_ARGUMENT = -1, -2, -3, -4, -5, -6, -7
+
+STATE_NEW, STATE_QUEUED, STATE_RUNNING, STATE_COMPLETED, STATE_ERROR = 1, 2, 3, 4, 5
+STATE_ABORT, STATE_SUBMITTED, STATE_TIMEOUT, STATE_NORESPONSE = 6, 7, 8, 9
+
+# every symbol include/havac_dev.h declares: (name, restype, argtypes)
+_vp, _u8p, _i8p = C.c_void_p, C.c_void_p, C.c_void_p
+SIGNATURES = {
+    "havac_dev_create": (C.c_int, [C.c_uint32, C.POINTER(C.c_void_p)]),
+    "havac_dev_destroy": (None, [_vp]),
+    "havac_dev_set_hit_capacity": (C.c_int, [_vp, C.c_uint64]),
+    "havac_dev_write_sequence": (C.c_int, [_vp, _u8p, C.c_uint64]),
+    "havac_dev_write_phmm": (C.c_int, [_vp, _i8p, C.c_uint64]),
+    "havac_dev_run_async": (C.c_int, [_vp]),
+    "havac_dev_state": (C.c_int, [_vp]),
+    "havac_dev_wait": (C.c_int, [_vp, C.c_uint32]),
+    "havac_dev_abort": (C.c_int, [_vp]),
+    "havac_dev_num_hits": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
+    "havac_dev_read_hits": (C.c_int, [_vp, C.c_void_p, C.c_uint32]),
+    "havac_dev_last_run_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "havac_dev_last_error": (C.c_char_p, [_vp]),
+    "havac_ssv_ctx_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "havac_ssv_ctx_destroy": (None, [_vp]),
+    "havac_ssv_enqueue": (C.c_int, [_vp, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "havac_ssv_finish": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "havac_ssv_sort_hits": (C.c_int, [_vp, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "havac_ssv_last_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "havac_ssv_shard_cells": (C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "havac_ssv_ctx_last_error": (C.c_char_p, [_vp]),
+    "havac_dev_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libhavac_dev.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with havac_amd/csrc/build.sh "
+                "(or __graft_entry__.build()); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Builds libhavac_dev.so (HIP kernels + C ABI) for gfx950.  Run from anywhere.
+set -e
+here="$(cd "$(dirname "$0")" && pwd)"
+out="$here/.."
+mkdir -p "$here/../../build"
+cd "$here/../../build"
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
+    -o "$out/libhavac_dev.so" "$here/havac_dev.hip" "$@"

@@ -1,0 +1,523 @@
+// havac_dev.hip -- C ABI of the MI355X device layer (include/havac_dev.h).
+//
+// Replaces the reference's XRT wrapper (host/HavacHwClient.cpp:25-202) and the
+// Vitis-HLS kernel it launches (device/HavacHls.cpp:20-43).  Host code here is
+// thin: argument checks with the reference's own limits, hipMalloc/hipMemcpy,
+// launches on a stream, HIP events.  There is no CPU fallback of any kind: if
+// HIP or a gfx950 device is missing every entry point fails with
+// HAVAC_E_NO_DEVICE / HAVAC_E_RUNTIME.
+#include "../../include/havac_dev.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <string.h>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "ssv_kernels.hip.h"
+
+using namespace havac;
+
+namespace {
+
+std::string hip_msg(const char* what, hipError_t e) {
+    return std::string(what) + ": " + hipGetErrorString(e);
+}
+
+#define HIP_TRY(ctx_err, expr)                                        \
+    do {                                                              \
+        hipError_t _e = (expr);                                       \
+        if (_e != hipSuccess) {                                       \
+            (ctx_err) = hip_msg(#expr, _e);                           \
+            return _e == hipErrorOutOfMemory ? HAVAC_E_NOMEM : HAVAC_E_RUNTIME; \
+        }                                                             \
+    } while (0)
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// ---- tiling of the diagonal axis ------------------------------------------
+struct Tiling {
+    uint32_t nrows_padded;
+    int64_t first_diag;
+    uint32_t ntiles;
+};
+
+Tiling make_tiling(uint64_t nsymbols, uint32_t nrows) {
+    Tiling t;
+    t.nrows_padded = round_up(nrows, kChunkRows);
+    t.first_diag = -(int64_t)t.nrows_padded;   // <= -(nrows-1), multiple of 32
+    uint64_t ndiag = nsymbols + t.nrows_padded;
+    t.ntiles = (uint32_t)((ndiag + kTileDiags - 1) / kTileDiags);
+    return t;
+}
+
+// rows a tile actually sweeps (same arithmetic as the kernel's p_lo / p_hi)
+int64_t tile_rows(const Tiling& t, uint64_t nsymbols, uint32_t tile) {
+    int64_t d0 = t.first_diag + (int64_t)tile * kTileDiags;
+    int64_t lo = -d0 - kTileDiags;
+    if (lo < 0) lo = 0;
+    int64_t hi = (int64_t)nsymbols - d0;
+    if (hi > (int64_t)t.nrows_padded) hi = t.nrows_padded;
+    return hi > lo ? hi - lo : 0;
+}
+
+// split tiles into shard_count runs of nearly equal swept rows
+void shard_tiles(const Tiling& t, uint64_t nsymbols, uint32_t shard_index, uint32_t shard_count,
+                 uint32_t* begin, uint32_t* end) {
+    if (shard_count <= 1) { *begin = 0; *end = t.ntiles; return; }
+    std::vector<int64_t> prefix(t.ntiles + 1, 0);
+    for (uint32_t i = 0; i < t.ntiles; i++) prefix[i + 1] = prefix[i] + tile_rows(t, nsymbols, i);
+    auto cut = [&](uint32_t k) -> uint32_t {
+        if (k == 0) return 0;
+        if (k >= shard_count) return t.ntiles;
+        int64_t target = prefix[t.ntiles] / shard_count * k;
+        uint32_t lo = 0, hi = t.ntiles;
+        while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (prefix[mid] < target) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    *begin = cut(shard_index);
+    *end = cut(shard_index + 1);
+}
+
+// cells (p, s) of the real matrix with s - p < D
+uint64_t cells_below_diag(uint64_t nsymbols, uint32_t nrows, int64_t D) {
+    uint64_t total = 0;
+    for (uint32_t p = 0; p < nrows; p++) {
+        int64_t c = D + (int64_t)p;
+        if (c < 0) c = 0;
+        if (c > (int64_t)nsymbols) c = (int64_t)nsymbols;
+        total += (uint64_t)c;
+    }
+    return total;
+}
+
+}  // namespace
+
+// ===========================================================================
+// Level 2: kernel ABI
+// ===========================================================================
+struct havac_ssv_ctx {
+    int device = 0;
+    uint2* rows16 = nullptr; size_t rows16_rows = 0;
+    void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+    uint64_t* sort_alt = nullptr; size_t sort_alt_count = 0;
+    unsigned long long* d_count = nullptr;
+    unsigned long long* h_count = nullptr;     // pinned
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // the pass enqueue() started and finish() completes
+    bool pending = false;
+    hipStream_t stream = nullptr;
+    uint64_t* d_hits = nullptr;
+    uint64_t hit_capacity = 0;
+    float ssv_ms = 0.f, total_ms = 0.f;
+    std::string err;
+};
+
+extern "C" const char* havac_dev_version(void) { return "havac_dev 0.1 gfx950"; }
+
+extern "C" int havac_ssv_ctx_create(havac_ssv_ctx** out) {
+    if (!out) return HAVAC_E_ARGUMENT;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return HAVAC_E_NO_DEVICE;
+    havac_ssv_ctx* c = new (std::nothrow) havac_ssv_ctx;
+    if (!c) return HAVAC_E_NOMEM;
+    std::string err;
+    auto fail = [&](int code) { havac_ssv_ctx_destroy(c); return code; };
+    if (hipGetDevice(&c->device) != hipSuccess) return fail(HAVAC_E_NO_DEVICE);
+    if (hipMalloc(&c->d_count, sizeof(unsigned long long)) != hipSuccess) return fail(HAVAC_E_NOMEM);
+    if (hipHostMalloc(&c->h_count, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return fail(HAVAC_E_NOMEM);
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+    *out = c;
+    return HAVAC_OK;
+}
+
+extern "C" void havac_ssv_ctx_destroy(havac_ssv_ctx* c) {
+    if (!c) return;
+    if (c->rows16) (void)hipFree(c->rows16);
+    if (c->sort_tmp) (void)hipFree(c->sort_tmp);
+    if (c->sort_alt) (void)hipFree(c->sort_alt);
+    if (c->d_count) (void)hipFree(c->d_count);
+    if (c->h_count) (void)hipHostFree(c->h_count);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    delete c;
+}
+
+extern "C" const char* havac_ssv_ctx_last_error(havac_ssv_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" uint64_t havac_ssv_shard_cells(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index,
+                                          uint32_t shard_count) {
+    if (nrows == 0 || nsymbols == 0) return 0;
+    if (shard_count <= 1) return nsymbols * (uint64_t)nrows;
+    Tiling t = make_tiling(nsymbols, nrows);
+    uint32_t b, e;
+    shard_tiles(t, nsymbols, shard_index, shard_count, &b, &e);
+    int64_t D0 = t.first_diag + (int64_t)b * kTileDiags, D1 = t.first_diag + (int64_t)e * kTileDiags;
+    return cells_below_diag(nsymbols, nrows, D1) - cells_below_diag(nsymbols, nrows, D0);
+}
+
+static int check_inputs(std::string& err, uint64_t nsymbols, uint32_t nrows) {
+    // host/HavacHwClient.cpp:81-97,112-125,142-147; device/HavacHls.hpp:19-20
+    if (nsymbols == 0) { err = "sequence length in segments cannot be 0, but 0 was given to the client."; return HAVAC_E_LENGTH; }
+    if (nrows == 0) { err = "phmm length in vectors cannot be 0, but 0 was given to the client."; return HAVAC_E_LENGTH; }
+    if (nsymbols % HAVAC_SEGMENT_COLUMNS != 0) {
+        err = "sequence length must be a multiple of the sequence segment length 12288 but sequence of length " +
+              std::to_string(nsymbols) + " was not";
+        return HAVAC_E_LENGTH;
+    }
+    if (nsymbols / 4 >= (4ull << 30)) { err = "compressed sequence size must be less than 4GiB"; return HAVAC_E_LENGTH; }
+    if (nrows >= (1u << 24)) { err = "model rows must be below 2^24 (24-bit row field of the hit record)"; return HAVAC_E_LENGTH; }
+    return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, uint64_t nsymbols,
+                                 const int8_t* d_phmm, uint32_t nrows, uint32_t shard_index,
+                                 uint32_t shard_count, uint64_t* d_hits, uint64_t hit_capacity,
+                                 const uint32_t* d_abort_flag, void* hip_stream) {
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (!d_sequence || !d_phmm || (!d_hits && hit_capacity) || shard_count == 0 || shard_index >= shard_count) {
+        c->err = "bad argument to havac_ssv_enqueue";
+        return HAVAC_E_ARGUMENT;
+    }
+    if (((uintptr_t)d_sequence & 7u) || ((uintptr_t)d_phmm & 3u)) {
+        c->err = "sequence must be 8-byte aligned and model 4-byte aligned";
+        return HAVAC_E_ARGUMENT;
+    }
+    if (c->pending) { c->err = "previous pass not finished: call havac_ssv_finish first"; return HAVAC_E_LOGIC; }
+    int rc = check_inputs(c->err, nsymbols, nrows);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    HIP_TRY(c->err, hipSetDevice(c->device));
+
+    Tiling t = make_tiling(nsymbols, nrows);
+    if (c->rows16_rows < t.nrows_padded) {
+        if (c->rows16) (void)hipFree(c->rows16);
+        c->rows16 = nullptr; c->rows16_rows = 0;
+        HIP_TRY(c->err, hipMalloc(&c->rows16, (size_t)t.nrows_padded * sizeof(uint2)));
+        c->rows16_rows = t.nrows_padded;
+    }
+    uint32_t tb, te;
+    shard_tiles(t, nsymbols, shard_index, shard_count, &tb, &te);
+
+    HIP_TRY(c->err, hipEventRecord(c->ev[0], stream));
+    HIP_TRY(c->err, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(ssv_expand_model, dim3((t.nrows_padded + 255) / 256), dim3(256), 0, stream,
+                       d_phmm, nrows, c->rows16, t.nrows_padded);
+    HIP_TRY(c->err, hipEventRecord(c->ev[1], stream));
+    if (te > tb) {
+        uint32_t nblocks = (te - tb + kWavesPerBlock - 1) / kWavesPerBlock;
+        hipLaunchKernelGGL(ssv_diag_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream,
+                           d_sequence, (int64_t)nsymbols, (const uint2*)c->rows16, t.nrows_padded, t.first_diag,
+                           tb, te, d_hits, c->d_count, hit_capacity, d_abort_flag);
+    }
+    HIP_TRY(c->err, hipEventRecord(c->ev[2], stream));
+    HIP_TRY(c->err, hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c->err, hipGetLastError());
+    c->pending = true; c->stream = stream; c->d_hits = d_hits; c->hit_capacity = hit_capacity;
+    return HAVAC_OK;
+}
+
+// radix sort of `count` keys held in `keys` (in place via the alt buffer), on `stream`
+static int sort_keys(havac_ssv_ctx* c, uint64_t* keys, uint64_t count, hipStream_t stream) {
+    if (count < 2) return HAVAC_OK;
+    if (c->sort_alt_count < count) {
+        if (c->sort_alt) (void)hipFree(c->sort_alt);
+        c->sort_alt = nullptr; c->sort_alt_count = 0;
+        size_t want = (size_t)count + count / 4 + 1024;
+        HIP_TRY(c->err, hipMalloc(&c->sort_alt, want * sizeof(uint64_t)));
+        c->sort_alt_count = want;
+    }
+    size_t need = 0;
+    HIP_TRY(c->err, rocprim::radix_sort_keys(nullptr, need, keys, c->sort_alt, (size_t)count, 0, 64, stream));
+    if (c->sort_tmp_bytes < need) {
+        if (c->sort_tmp) (void)hipFree(c->sort_tmp);
+        c->sort_tmp = nullptr; c->sort_tmp_bytes = 0;
+        HIP_TRY(c->err, hipMalloc(&c->sort_tmp, need + need / 4));
+        c->sort_tmp_bytes = need + need / 4;
+    }
+    size_t bytes = c->sort_tmp_bytes;
+    HIP_TRY(c->err, rocprim::radix_sort_keys(c->sort_tmp, bytes, keys, c->sort_alt, (size_t)count, 0, 64, stream));
+    HIP_TRY(c->err, hipMemcpyAsync(keys, c->sort_alt, count * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
+    return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_finish(havac_ssv_ctx* c, uint64_t* hit_count_out) {
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (!c->pending) { c->err = "no pass enqueued"; return HAVAC_E_LOGIC; }
+    c->pending = false;
+    HIP_TRY(c->err, hipSetDevice(c->device));
+    HIP_TRY(c->err, hipStreamSynchronize(c->stream));
+    uint64_t found = *c->h_count;
+    uint64_t stored = found < c->hit_capacity ? found : c->hit_capacity;
+    int rc = sort_keys(c, c->d_hits, stored, c->stream);
+    if (rc) return rc;
+    if (stored)
+        hipLaunchKernelGGL(ssv_keys_to_records, dim3((unsigned)((stored + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_hits, stored);
+    HIP_TRY(c->err, hipEventRecord(c->ev[3], c->stream));
+    HIP_TRY(c->err, hipStreamSynchronize(c->stream));
+    HIP_TRY(c->err, hipEventElapsedTime(&c->ssv_ms, c->ev[1], c->ev[2]));
+    HIP_TRY(c->err, hipEventElapsedTime(&c->total_ms, c->ev[0], c->ev[3]));
+    if (hit_count_out) *hit_count_out = found;
+    if (found > c->hit_capacity) {
+        c->err = "hit buffer overflow: " + std::to_string(found) + " hits found, capacity " + std::to_string(c->hit_capacity);
+        return HAVAC_E_HIT_OVERFLOW;
+    }
+    return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_sort_hits(havac_ssv_ctx* c, uint64_t* d_hits, uint64_t count, void* hip_stream) {
+    if (!c || (!d_hits && count)) return HAVAC_E_ARGUMENT;
+    if (count == 0) return HAVAC_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    HIP_TRY(c->err, hipSetDevice(c->device));
+    unsigned nb = (unsigned)((count + 255) / 256);
+    hipLaunchKernelGGL(ssv_records_to_keys, dim3(nb), dim3(256), 0, stream, d_hits, count);
+    int rc = sort_keys(c, d_hits, count, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ssv_keys_to_records, dim3(nb), dim3(256), 0, stream, d_hits, count);
+    HIP_TRY(c->err, hipGetLastError());
+    return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_last_ms(havac_ssv_ctx* c, float* ssv_kernel_ms, float* total_ms) {
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (ssv_kernel_ms) *ssv_kernel_ms = c->ssv_ms;
+    if (total_ms) *total_ms = c->total_ms;
+    return HAVAC_OK;
+}
+
+// ===========================================================================
+// Level 1: handle API (class HavacHwClient)
+// ===========================================================================
+struct havac_dev {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    havac_ssv_ctx* ctx = nullptr;
+    uint8_t* d_seq = nullptr; uint64_t seq_bytes = 0; uint64_t seq_alloc = 0;
+    int8_t* d_phmm = nullptr; uint64_t phmm_bytes = 0; uint64_t phmm_alloc = 0;
+    uint64_t* d_hits = nullptr; uint64_t hit_capacity = 0;
+    uint32_t* h_abort = nullptr;        // pinned, mapped: the kernel polls it
+    uint32_t* d_abort = nullptr;
+    hipEvent_t done = nullptr;
+    bool has_run = false, finished = false, aborted = false, failed = false;
+    uint64_t found = 0;
+    std::string err;
+};
+
+static const uint64_t kDefaultHitCapacity = 16ull << 20;
+
+static int dev_alloc_hits(havac_dev* d, uint64_t cap) {
+    if (d->d_hits) { (void)hipFree(d->d_hits); d->d_hits = nullptr; d->hit_capacity = 0; }
+    HIP_TRY(d->err, hipMalloc(&d->d_hits, cap * sizeof(uint64_t)));
+    d->hit_capacity = cap;
+    return HAVAC_OK;
+}
+
+extern "C" int havac_dev_create(uint32_t device_index, havac_dev** out) {
+    if (!out) return HAVAC_E_ARGUMENT;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || (int)device_index >= ndev) return HAVAC_E_NO_DEVICE;
+    havac_dev* d = new (std::nothrow) havac_dev;
+    if (!d) return HAVAC_E_NOMEM;
+    d->device = (int)device_index;
+    auto fail = [&](int code) { havac_dev_destroy(d); return code; };
+    if (hipSetDevice(d->device) != hipSuccess) return fail(HAVAC_E_NO_DEVICE);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d->device) != hipSuccess) return fail(HAVAC_E_NO_DEVICE);
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(HAVAC_E_NO_DEVICE);   // the code object is gfx950 only
+    if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+    if (havac_ssv_ctx_create(&d->ctx) != HAVAC_OK) return fail(HAVAC_E_RUNTIME);
+    if (hipHostMalloc(&d->h_abort, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return fail(HAVAC_E_NOMEM);
+    *d->h_abort = 0;
+    if (hipHostGetDevicePointer((void**)&d->d_abort, d->h_abort, 0) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+    if (hipEventCreateWithFlags(&d->done, hipEventDisableTiming) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+    if (dev_alloc_hits(d, kDefaultHitCapacity) != HAVAC_OK) return fail(HAVAC_E_NOMEM);
+    *out = d;
+    return HAVAC_OK;
+}
+
+extern "C" void havac_dev_destroy(havac_dev* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    if (d->stream) (void)hipStreamSynchronize(d->stream);
+    if (d->ctx) havac_ssv_ctx_destroy(d->ctx);
+    if (d->d_seq) (void)hipFree(d->d_seq);
+    if (d->d_phmm) (void)hipFree(d->d_phmm);
+    if (d->d_hits) (void)hipFree(d->d_hits);
+    if (d->h_abort) (void)hipHostFree(d->h_abort);
+    if (d->done) (void)hipEventDestroy(d->done);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+}
+
+extern "C" const char* havac_dev_last_error(havac_dev* d) { return d ? d->err.c_str() : "null handle"; }
+
+extern "C" int havac_dev_set_hit_capacity(havac_dev* d, uint64_t max_hits) {
+    if (!d || max_hits == 0) return HAVAC_E_ARGUMENT;
+    if (d->has_run && !d->finished) { d->err = "cannot resize the hit buffer during a run"; return HAVAC_E_LOGIC; }
+    HIP_TRY(d->err, hipSetDevice(d->device));
+    return dev_alloc_hits(d, max_hits);
+}
+
+template <typename T>
+static int upload(havac_dev* d, T** buf, uint64_t* alloc, const void* src, uint64_t nbytes) {
+    HIP_TRY(d->err, hipSetDevice(d->device));
+    if (*alloc < nbytes) {
+        if (*buf) (void)hipFree(*buf);
+        *buf = nullptr; *alloc = 0;
+        HIP_TRY(d->err, hipMalloc(buf, nbytes));
+        *alloc = nbytes;
+    }
+    HIP_TRY(d->err, hipMemcpyAsync(*buf, src, nbytes, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(d->err, hipStreamSynchronize(d->stream));
+    return HAVAC_OK;
+}
+
+extern "C" int havac_dev_write_sequence(havac_dev* d, const uint8_t* packed, uint64_t nbytes) {
+    if (!d || (!packed && nbytes)) return HAVAC_E_ARGUMENT;
+    // host/HavacHwClient.cpp:81-97 (the reference computes the symbol count in 32 bits; we do not wrap)
+    uint64_t nsym = nbytes * 4;
+    if (nsym % HAVAC_SEGMENT_COLUMNS != 0) {
+        d->err = "sequence length must be a multiple of the sequence segment length 12288 but sequence of length " +
+                 std::to_string(nsym) + " was not \n";
+        return HAVAC_E_LENGTH;
+    }
+    if (nbytes >= (4ull << 30)) {
+        d->err = "compressed sequence size must be less than 4GiB. length requested: " + std::to_string(nbytes) + " bytes.";
+        return HAVAC_E_LENGTH;
+    }
+    d->seq_bytes = nbytes;
+    if (nbytes == 0) return HAVAC_OK;
+    return upload(d, &d->d_seq, &d->seq_alloc, packed, nbytes);
+}
+
+extern "C" int havac_dev_write_phmm(havac_dev* d, const int8_t* scores, uint64_t nbytes) {
+    if (!d || (!scores && nbytes)) return HAVAC_E_ARGUMENT;
+    // host/HavacHwClient.cpp:112-125
+    if (nbytes % 4 != 0) {
+        d->err = "phmm of length length " + std::to_string(nbytes) +
+                 " was given, but was not divisible by 4. only nucleotide phmms with 4 scores/position is supported.\n";
+        return HAVAC_E_LENGTH;
+    }
+    if (nbytes >= (1ull << 30)) {
+        d->err = "model length must be less than 1MiB (model length < 1024*1024). length requested: " +
+                 std::to_string(nbytes) + " bytes.";
+        return HAVAC_E_LENGTH;
+    }
+    d->phmm_bytes = nbytes;
+    if (nbytes == 0) return HAVAC_OK;
+    return upload(d, &d->d_phmm, &d->phmm_alloc, scores, nbytes);
+}
+
+extern "C" int havac_dev_run_async(havac_dev* d) {
+    if (!d) return HAVAC_E_ARGUMENT;
+    // host/HavacHwClient.cpp:142-147
+    if (d->seq_bytes == 0) { d->err = "sequence length in segments cannot be 0, but 0 was given to the client."; return HAVAC_E_LENGTH; }
+    if (d->phmm_bytes == 0) { d->err = "phmm length in vectors cannot be 0, but 0 was given to the client."; return HAVAC_E_LENGTH; }
+    if (d->has_run && !d->finished) { d->err = "a run is already in flight"; return HAVAC_E_LOGIC; }
+    HIP_TRY(d->err, hipSetDevice(d->device));
+    *d->h_abort = 0;
+    d->aborted = false; d->failed = false; d->finished = false; d->found = 0;
+    int rc = havac_ssv_enqueue(d->ctx, d->d_seq, d->seq_bytes * 4, d->d_phmm, (uint32_t)(d->phmm_bytes / 4), 0, 1,
+                               d->d_hits, d->hit_capacity, d->d_abort, d->stream);
+    if (rc) { d->err = havac_ssv_ctx_last_error(d->ctx); return rc; }
+    HIP_TRY(d->err, hipEventRecord(d->done, d->stream));
+    d->has_run = true;
+    return HAVAC_OK;
+}
+
+// completes a drained run: orders the hits
+static int dev_finish(havac_dev* d) {
+    if (d->finished) return d->failed ? HAVAC_STATE_ERROR : (d->aborted ? HAVAC_STATE_ABORT : HAVAC_STATE_COMPLETED);
+    uint64_t found = 0;
+    int rc = havac_ssv_finish(d->ctx, &found);
+    d->finished = true;
+    d->found = found;
+    d->aborted = (*d->h_abort != 0);
+    if (rc != HAVAC_OK) {
+        d->err = havac_ssv_ctx_last_error(d->ctx);
+        d->failed = true;
+        return HAVAC_STATE_ERROR;
+    }
+    return d->aborted ? HAVAC_STATE_ABORT : HAVAC_STATE_COMPLETED;
+}
+
+extern "C" int havac_dev_state(havac_dev* d) {
+    if (!d) return HAVAC_E_ARGUMENT;
+    if (!d->has_run) {   // host/HavacHwClient.cpp:168
+        d->err = "run object was not initialized. run function invokeHavacSsvAsync to initialize this object.";
+        return HAVAC_E_LOGIC;
+    }
+    if (d->finished) return d->failed ? HAVAC_STATE_ERROR : (d->aborted ? HAVAC_STATE_ABORT : HAVAC_STATE_COMPLETED);
+    hipError_t q = hipEventQuery(d->done);
+    if (q == hipErrorNotReady) return HAVAC_STATE_RUNNING;
+    if (q != hipSuccess) { d->err = hip_msg("hipEventQuery", q); return HAVAC_STATE_ERROR; }
+    return dev_finish(d);
+}
+
+extern "C" int havac_dev_wait(havac_dev* d, uint32_t timeout_ms) {
+    if (!d) return HAVAC_E_ARGUMENT;
+    if (!d->has_run) { d->err = "no run to wait for"; return HAVAC_E_LOGIC; }
+    if (d->finished) return havac_dev_state(d);
+    if (timeout_ms == 0) {
+        hipError_t e = hipEventSynchronize(d->done);
+        if (e != hipSuccess) { d->err = hip_msg("hipEventSynchronize", e); d->finished = true; d->failed = true; return HAVAC_STATE_ERROR; }
+        return dev_finish(d);
+    }
+    auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
+    for (;;) {
+        hipError_t q = hipEventQuery(d->done);
+        if (q == hipSuccess) return dev_finish(d);
+        if (q != hipErrorNotReady) { d->err = hip_msg("hipEventQuery", q); d->finished = true; d->failed = true; return HAVAC_STATE_ERROR; }
+        if (std::chrono::steady_clock::now() >= deadline) return HAVAC_STATE_TIMEOUT;
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+}
+
+extern "C" int havac_dev_abort(havac_dev* d) {
+    if (!d) return HAVAC_E_ARGUMENT;
+    if (!d->has_run) { d->err = "no run to abort"; return HAVAC_E_LOGIC; }
+    if (d->finished) return havac_dev_state(d);
+    if (hipEventQuery(d->done) == hipSuccess) return dev_finish(d);
+    *d->h_abort = 1;
+    __sync_synchronize();
+    hipError_t e = hipEventSynchronize(d->done);
+    if (e != hipSuccess) { d->err = hip_msg("hipEventSynchronize", e); d->finished = true; d->failed = true; return HAVAC_STATE_ERROR; }
+    return dev_finish(d);
+}
+
+extern "C" int havac_dev_num_hits(havac_dev* d, uint32_t* count) {
+    if (!d || !count) return HAVAC_E_ARGUMENT;
+    if (!d->has_run) { d->err = "num hits was not set by the client!"; return HAVAC_E_RUNTIME; }   // HavacHwClient.cpp:181-183
+    if (!d->finished) { int s = havac_dev_wait(d, 0); if (s < 0) return s; }
+    if (d->failed) return d->found > d->hit_capacity ? HAVAC_E_HIT_OVERFLOW : HAVAC_E_RUNTIME;
+    *count = (uint32_t)d->found;
+    return HAVAC_OK;
+}
+
+extern "C" int havac_dev_read_hits(havac_dev* d, uint64_t* out, uint32_t n) {
+    if (!d || (!out && n)) return HAVAC_E_ARGUMENT;
+    uint32_t have = 0;
+    int rc = havac_dev_num_hits(d, &have);
+    if (rc) return rc;
+    if (n > have) n = have;
+    if (n == 0) return HAVAC_OK;
+    HIP_TRY(d->err, hipSetDevice(d->device));
+    HIP_TRY(d->err, hipMemcpy(out, d->d_hits, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return HAVAC_OK;
+}
+
+extern "C" int havac_dev_last_run_ms(havac_dev* d, float* ssv_kernel_ms, float* total_ms) {
+    if (!d) return HAVAC_E_ARGUMENT;
+    if (!d->has_run || !d->finished) { d->err = "no finished run"; return HAVAC_E_LOGIC; }
+    return havac_ssv_last_ms(d->ctx, ssv_kernel_ms, total_ms);
+}

@@ -1,0 +1,257 @@
+// ssv_kernels.hip.h -- CDNA4 (gfx950) kernels of the SSV filter.
+//
+// What is computed (reference: device/HavacHls.cpp:220-402, oracle form
+// test/softSsv/SoftSsv.cpp:31-62):
+//     S[p][s] = S[p-1][s-1] + M[p][seq[s]]      (0 on row 0 / column 0)
+//     S < 0 -> 0 ;  S >= 256 -> report (p, s), S = 0
+//
+// How it is laid out here (nothing like the FPGA's systolic row of 12288 PEs):
+//
+//  * DIAGONAL-STATIONARY.  A cell depends only on its own diagonal d = s - p,
+//    so a lane owns 32 adjacent diagonals for the whole height of the matrix
+//    and its scores never move.  No inter-lane shuffle, no inter-tile carry
+//    (the FPGA's scoreQueue, device/HavacHls.cpp:451-465, disappears) and no
+//    halo between GPUs.  A wave owns 64 x 32 = 2048 diagonals (a "tile").
+//  * TWO CELLS PER VGPR as packed int16 holding (score - 32768): one
+//    v_pk_add_i16 with clamp is add + clamp-at-zero, and a crossing of 256 is
+//    bit 8 of the unbiased score (scores never exceed 255 + 127).
+//  * MATCH SCORES BY v_perm_b32.  The model row is widened once to four int16
+//    (8 bytes, {A,C | G,T}); the 2-bit symbols of a diagonal pair are expanded
+//    once per 32-row chunk into a byte selector [2a,2a+1,2b,2b+1], so one
+//    v_perm_b32 yields both sign-extended match scores.  The symbol window
+//    slides one position per row; even rows use the aligned selector words,
+//    odd rows the words shifted by 16 bits (v_alignbit), both indexed
+//    statically in the fully unrolled 32-row chunk, so the slide costs nothing.
+//  * OUTSIDE THE MATRIX (columns < 0 or >= N, rows >= nrows) the selector
+//    / row yields a large negative score, which pins the cell at 0 and can
+//    never hit: no per-cell predicate anywhere in the hot loop.
+//  * HITS are rare (about 1e-5 per cell on Dfam-like models): the 16 score
+//    registers are OR-ed, one wave-wide test per row finds bit 8, and only then
+//    the slow path emits and resets.  Records are appended through one atomic
+//    per wave-row and ordered afterwards (ssv_order_* below).
+//
+// Roofline: integer VALU issue; HBM traffic is
+// N/4 + 8*rows bytes per tile sweep, thousands of cells per byte.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <utility>
+
+namespace havac {
+
+constexpr int kDiagsPerLane = 32;                 // 16 VGPRs x 2 int16
+constexpr int kRegs = kDiagsPerLane / 2;
+constexpr int kTileDiags = 64 * kDiagsPerLane;    // one wave
+constexpr int kChunkRows = 32;                    // rows per unrolled chunk
+constexpr int kWavesPerBlock = 4;
+constexpr uint32_t kScoreZero = 0x80008000u;      // two cells at score 0 (bias -32768)
+constexpr uint32_t kHitBits = 0x01000100u;        // bit 8 of either unbiased score
+constexpr uint32_t kPadSelector = 0x0d0c0d0cu;    // v_perm: bytes (0x00,0xFF) -> int16 -256 twice
+
+// sort key of a hit: (segment, row, column-in-segment) -- the FPGA's emission
+// order (device/HavacHls.cpp:151-152,264; device/HitReporting.cpp:178-337)
+__device__ __forceinline__ uint64_t hit_key(uint32_t row, uint64_t column) {
+    uint64_t seg = column / 12288u;
+    uint64_t in_seg = column - seg * 12288u;
+    return (seg << 38) | ((uint64_t)row << 14) | in_seg;
+}
+
+// key -> the reference's packed record (device/HitReporting.cpp:421-430)
+__device__ __forceinline__ uint64_t key_to_record(uint64_t key) {
+    uint64_t in_seg = key & 0x3fffull;
+    uint64_t row = (key >> 14) & 0xffffffull;
+    uint64_t seg = key >> 38;
+    return in_seg | (seg << 14) | (row << 40);
+}
+__device__ __forceinline__ uint64_t record_to_key(uint64_t rec) {
+    uint64_t in_seg = rec & 0x3fffull;
+    uint64_t seg = (rec >> 14) & 0x3ffffffull;
+    uint64_t row = rec >> 40;
+    return (seg << 38) | (row << 14) | in_seg;
+}
+
+// ---------------------------------------------------------------------------
+// model int8 [row][A,C,G,T]  ->  int16 x4 per row, padded with rows of -128 up
+// to a whole number of chunks (a padding row can only lower a score).
+// Replaces nothing in the reference: the FPGA muxes bytes directly
+// (device/HavacHls.cpp:429-442); this is the layout v_perm_b32 wants.
+__global__ void ssv_expand_model(const int8_t* __restrict__ phmm, uint32_t nrows,
+                                 uint2* __restrict__ rows16, uint32_t nrows_padded) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows_padded) return;
+    int a = -128, c = -128, g = -128, t = -128;
+    if (r < nrows) {
+        uint32_t w = reinterpret_cast<const uint32_t*>(phmm)[r];
+        a = (int8_t)(w & 0xff); c = (int8_t)((w >> 8) & 0xff);
+        g = (int8_t)((w >> 16) & 0xff); t = (int8_t)(w >> 24);
+    }
+    uint2 o;
+    o.x = ((uint32_t)a & 0xffffu) | ((uint32_t)c << 16);
+    o.y = ((uint32_t)g & 0xffffu) | ((uint32_t)t << 16);
+    rows16[r] = o;
+}
+
+// ---------------------------------------------------------------------------
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t sat_add_pk16(uint32_t a, uint32_t b) {
+    short2v r = __builtin_elementwise_add_sat(__builtin_bit_cast(short2v, a),
+                                              __builtin_bit_cast(short2v, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+// selector word for the symbol pair in bits [3:0] of `nib`: bytes
+// [2a, 2a+1, 2b, 2b+1] (a = low symbol)
+__device__ __forceinline__ uint32_t pair_selector(uint32_t w, int shift) {
+    uint32_t a = (w >> shift) & 3u;
+    uint32_t b = (w >> (shift + 2)) & 3u;
+    return ((b * 0x0202u) << 16) + (a * 0x0202u + 0x01000100u);   // 24-bit multiplies + v_lshl_add
+}
+
+// 8 bytes = 32 symbols at symbol offset `pos` (multiple of 32); zero outside the buffer
+__device__ __forceinline__ uint2 load_symbols(const uint8_t* __restrict__ seq, int64_t nsymbols, int64_t pos,
+                                              bool checked) {
+    if (checked && (pos < 0 || pos + 32 > nsymbols)) return make_uint2(0u, 0u);
+    return *reinterpret_cast<const uint2*>(seq + (pos >> 2));
+}
+
+// Slow path, reached only by waves that saw bit 8 in some score this row.
+// One bit per diagonal of this lane; the column of bit b is column0 + b.
+__device__ __noinline__ void emit_hits(uint64_t* __restrict__ hits, unsigned long long* __restrict__ hit_count,
+                                       uint64_t hit_capacity, uint32_t mask, uint32_t row, int64_t column0) {
+    while (mask) {
+        int b = __builtin_ctz(mask);
+        mask &= mask - 1;
+        unsigned long long idx = atomicAdd(hit_count, 1ull);
+        if (idx < hit_capacity) hits[idx] = hit_key(row, (uint64_t)(column0 + b));
+    }
+}
+
+// The expanded model is read through the constant address space: the address
+// is wave-uniform, so hipcc emits s_load_dwordx* into SGPRs (no VGPR, no
+// vmcnt wait in the row loop).  Legal because the kernel never writes it.
+typedef uint32_t row16_t __attribute__((ext_vector_type(2)));   // {A,C} , {G,T} as int16 pairs
+typedef const __attribute__((address_space(4))) row16_t* const_rows_t;
+
+struct HitSink {
+    uint64_t* hits;
+    unsigned long long* hit_count;
+    uint64_t hit_capacity;
+};
+
+// One model row over the lane's 32 diagonals.  R is the row inside the chunk:
+// a template parameter so that every selector index is a compile-time constant
+// and the sliding symbol window costs no instruction.
+template <int R>
+__device__ __forceinline__ void row_step(uint32_t (&x)[kRegs], const uint32_t (&W)[32], const uint32_t (&Wodd)[31],
+                                         const row16_t row, const HitSink& sink, uint32_t p0, int64_t column0) {
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < kRegs; i++) {
+        const uint32_t sel = (R & 1) ? Wodd[(R >> 1) + i] : W[(R >> 1) + i];
+        const uint32_t m = __builtin_amdgcn_perm(row.y, row.x, sel);
+        x[i] = sat_add_pk16(x[i], m);
+        any |= x[i];
+    }
+    if (__builtin_expect(__any((any & kHitBits) != 0), 0)) {
+        uint32_t mask = 0;
+#pragma unroll
+        for (int i = 0; i < kRegs; i++) {
+            const uint32_t h = x[i] & kHitBits;
+            if (h & 0x100u) { mask |= 1u << (2 * i); x[i] = (x[i] & 0xffff0000u) | 0x8000u; }
+            if (h & 0x1000000u) { mask |= 2u << (2 * i); x[i] = (x[i] & 0x0000ffffu) | 0x80000000u; }
+        }
+        if (mask) emit_hits(sink.hits, sink.hit_count, sink.hit_capacity, mask, p0 + R, column0 + R);
+    }
+}
+
+template <int... R>
+__device__ __forceinline__ void chunk_rows(uint32_t (&x)[kRegs], const uint32_t (&W)[32], const uint32_t (&Wodd)[31],
+                                           const_rows_t rows, const HitSink& sink, uint32_t p0,
+                                           int64_t column0, std::integer_sequence<int, R...>) {
+    // all rows of the chunk are fetched up front (one batch of scalar loads, one wait) rather than
+    // one dependent s_load per row
+    row16_t row[kChunkRows];
+#pragma unroll
+    for (int r = 0; r < kChunkRows; r++) row[r] = rows[r];
+    (row_step<R>(x, W, Wodd, row[R], sink, p0, column0), ...);
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock)
+void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, const uint2* __restrict__ rows16,
+                     const uint32_t nrows_padded, const int64_t first_diag, const uint32_t tile_begin,
+                     const uint32_t tile_end, uint64_t* __restrict__ hits, unsigned long long* __restrict__ hit_count,
+                     const uint64_t hit_capacity, const uint32_t* __restrict__ abort_flag) {
+    const int lane = threadIdx.x & 63;
+    // readfirstlane: everything derived from the tile index is wave-uniform, which lets hipcc keep
+    // the row pointer in SGPRs (scalar loads of the model rows) and branch on `edge` with SALU
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = tile_begin + blockIdx.x * kWavesPerBlock + wave;
+    if (tile >= tile_end) return;
+    const HitSink sink{hits, hit_count, hit_capacity};
+
+    const int64_t d0 = first_diag + (int64_t)tile * kTileDiags;     // wave's first diagonal
+    const int64_t dl = d0 + lane * kDiagsPerLane;                   // lane's first diagonal
+    // rows whose cells of this tile can lie inside the matrix
+    int64_t p_lo = -d0 - kTileDiags;                                // first chunk touching column >= 0
+    if (p_lo < 0) p_lo = 0;
+    int64_t p_hi = nsymbols - d0;                                   // first chunk entirely at columns >= N
+    if (p_hi > (int64_t)nrows_padded) p_hi = nrows_padded;
+    if (p_lo >= p_hi) return;
+
+    uint32_t x[kRegs];
+#pragma unroll
+    for (int i = 0; i < kRegs; i++) x[i] = kScoreZero;
+
+    // symbol window of the current chunk: positions [j, j+64), j = dl + p0
+    bool edge = (d0 + p_lo < 0) || (d0 + p_lo + kTileDiags + kChunkRows > nsymbols);
+    uint2 hi = load_symbols(seq, nsymbols, dl + p_lo, edge);
+
+    for (int64_t p0 = p_lo; p0 < p_hi; p0 += kChunkRows) {
+        if (abort_flag && ((p0 & 2047) == 0) &&
+            __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+        const int64_t j = dl + p0;
+        edge = (d0 + p0 < 0) || (d0 + p0 + kTileDiags + kChunkRows > nsymbols);
+        const uint2 lo = hi;
+        hi = load_symbols(seq, nsymbols, j + 32, edge);
+
+        // selectors: W[k] for symbols (2k, 2k+1), Wodd[k] for (2k+1, 2k+2)
+        uint32_t W[32], Wodd[31];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            W[k] = pair_selector(lo.x, k * 4);
+            W[k + 8] = pair_selector(lo.y, k * 4);
+            W[k + 16] = pair_selector(hi.x, k * 4);
+            W[k + 24] = pair_selector(hi.y, k * 4);
+        }
+        if (edge) {
+            // positions outside [0, N) score -256: pins the cell at 0, never hits
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const int64_t pos = j + 2 * k;     // pos and pos+1 are in or out together (j, N even)
+                if (pos < 0 || pos >= nsymbols) W[k] = kPadSelector;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 31; k++) {
+            Wodd[k] = __builtin_amdgcn_alignbit(W[k + 1], W[k], 16);
+            asm volatile("" : "+v"(Wodd[k]));   // keep it in a VGPR: hipcc otherwise recomputes it in every odd row
+        }
+
+        chunk_rows(x, W, Wodd, (const_rows_t)(const row16_t*)(rows16 + p0), sink, (uint32_t)p0, dl + p0,
+                   std::make_integer_sequence<int, kChunkRows>{});
+    }
+}
+
+// ---------------------------------------------------------------------------
+// after the radix sort of the keys: rewrite them as the reference's records
+__global__ void ssv_keys_to_records(uint64_t* __restrict__ hits, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) hits[i] = key_to_record(hits[i]);
+}
+__global__ void ssv_records_to_keys(uint64_t* __restrict__ hits, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) hits[i] = record_to_key(hits[i]);
+}
+
+}  // namespace havac

@@ -1,0 +1,129 @@
+"""Python mirror of the reference's `HavacHwClient` on top of the C ABI.
+
+Same method names, argument meaning and error behaviour as
+host/HavacHwClient.hpp:22-75 / host/HavacHwClient.cpp:25-202, so that the
+parity tests read like the reference's own.  All work happens in
+libhavac_dev.so on the GPU; this file only moves numpy buffers across ctypes
+and maps error codes back to the exception types the reference throws.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class LengthError(ValueError):
+    """std::length_error (host/HavacHwClient.cpp:88,96,118,124,143,146)."""
+
+
+class LogicError(RuntimeError):
+    """std::logic_error (host/HavacHwClient.cpp:168)."""
+
+
+class HitOverflowError(RuntimeError):
+    """HAVAC_E_HIT_OVERFLOW: more hits than the hit buffer holds."""
+
+
+class NoDeviceError(RuntimeError):
+    """No usable gfx950 device."""
+
+
+def raise_for(code: int, message: str):
+    if code >= 0:
+        return
+    if code == _lib.E_LENGTH:
+        raise LengthError(message)
+    if code == _lib.E_LOGIC:
+        raise LogicError(message)
+    if code == _lib.E_NOMEM:
+        raise MemoryError(message)
+    if code == _lib.E_HIT_OVERFLOW:
+        raise HitOverflowError(message)
+    if code == _lib.E_NO_DEVICE:
+        raise NoDeviceError(message or "no gfx950 device")
+    if code == _lib.E_ARGUMENT:
+        raise ValueError(message or "bad argument")
+    raise RuntimeError(message or f"havac_dev error {code}")
+
+
+class HavacHwClient:
+    """HavacHwClient(xclbinFileSrc, havacKernelName, deviceIndex) -- the first two are accepted and
+    ignored: there is no bitstream, the kernels live in libhavac_dev.so."""
+
+    def __init__(self, xclbinFileSrc: str = "", havacKernelName: str = "HavacKernel", deviceIndex: int = 0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        rc = self._L.havac_dev_create(deviceIndex, C.byref(h))
+        if rc != 0:
+            raise_for(rc, "could not create the device client")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.havac_dev_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise_for(rc, (self._L.havac_dev_last_error(self._h) or b"").decode())
+        return rc
+
+    def setHitCapacity(self, max_hits: int):
+        self._check(self._L.havac_dev_set_hit_capacity(self._h, int(max_hits)))
+
+    def writeSequence(self, compressedSequence):
+        buf = np.ascontiguousarray(compressedSequence, dtype=np.uint8)
+        self._check(self._L.havac_dev_write_sequence(self._h, buf.ctypes.data, buf.size))
+
+    def writePhmm(self, phmmAsFlattenedArray):
+        buf = np.ascontiguousarray(phmmAsFlattenedArray, dtype=np.int8).reshape(-1)
+        self._check(self._L.havac_dev_write_phmm(self._h, buf.ctypes.data, buf.size))
+
+    def invokeHavacSsvAsync(self):
+        self._check(self._L.havac_dev_run_async(self._h))
+
+    def getHwState(self) -> int:
+        return self._check(self._L.havac_dev_state(self._h))
+
+    def waitForHavacSsvAsync(self, timeout_ms: int = 0) -> int:
+        return self._check(self._L.havac_dev_wait(self._h, int(timeout_ms)))
+
+    def abort(self) -> int:
+        return self._check(self._L.havac_dev_abort(self._h))
+
+    def getNumHits(self) -> int:
+        n = C.c_uint32(0)
+        self._check(self._L.havac_dev_num_hits(self._h, C.byref(n)))
+        return n.value
+
+    def getHitList(self) -> np.ndarray:
+        n = self.getNumHits()
+        out = np.empty(n, dtype=np.uint64)
+        if n:
+            self._check(self._L.havac_dev_read_hits(self._h, out.ctypes.data, n))
+        return out
+
+    def lastRunMs(self):
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(self._L.havac_dev_last_run_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+def run_ssv(packed_sequence, model, device: int = 0, hit_capacity: int | None = None) -> np.ndarray:
+    """Convenience: one whole run through the handle API; hits in device order."""
+    c = HavacHwClient(deviceIndex=device)
+    try:
+        if hit_capacity:
+            c.setHitCapacity(hit_capacity)
+        c.writeSequence(packed_sequence)
+        c.writePhmm(model)
+        c.invokeHavacSsvAsync()
+        c.waitForHavacSsvAsync()
+        return c.getHitList()
+    finally:
+        c.close()

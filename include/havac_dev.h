@@ -1,0 +1,197 @@
+/*
+ * havac_dev.h -- C ABI of the MI355X device layer for HAVAC's SSV filter.
+ *
+ * This is the drop-in boundary: it replaces the reference's XRT wrapper
+ * `HavacHwClient` (host/HavacHwClient.hpp:22-75, host/HavacHwClient.cpp:25-202)
+ * and, below it, the Vitis-HLS kernel `HavacKernel` (device/HavacHls.cpp:20-43).
+ * Plain pointers and sizes only; no C++, HIP or torch types cross it.  The
+ * reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Two levels are exported by libhavac_dev.so:
+ *
+ *  1. havac_dev_*   one opaque handle per `Havac` object; one entry point per
+ *                   HavacHwClient method the `Havac` class calls
+ *                   (host/Havac.cpp:24,53,75,93,97,101,146,191).  The handle
+ *                   owns its device buffers, as HavacHwClient owns its xrt::bo's.
+ *  2. havac_ssv_*   the kernel ABI itself on caller-owned DEVICE memory and a
+ *                   caller-owned HIP stream: the counterpart of calling
+ *                   HavacKernel(seq, nSeg, phmm, sumL, hits, hitCount) directly
+ *                   (device/HavacHls.cpp:20-43).  Used by bench.py and by the
+ *                   multi-GPU driver, which keep inputs resident in HBM.
+ *
+ * Data contracts (identical to the reference's):
+ *   sequence  2-bit packed, 4 symbols per byte, symbol i in byte i/4 at bits
+ *             (i%4)*2, A=0 C=1 G=2 T=3 (host/sequence/SequencePreprocessor.cpp:46-70);
+ *             symbol count a multiple of 12288 (host/HavacHwClient.cpp:81-90);
+ *             fewer than 4 GiB of packed bytes (host/HavacHwClient.cpp:92-97).
+ *   model     flattened int8 [row][A,C,G,T], all models of the .hmm file back to
+ *             back (host/phmm/PhmmPreprocessor.cpp:9-31); byte count a multiple
+ *             of 4 and below 1 GiB (host/HavacHwClient.cpp:112-125); rows < 2^24
+ *             (device/HavacHls.hpp:19).
+ *   hits      packed 64-bit records: [13:0] column inside its 12288-column
+ *             segment, [39:14] segment index, [63:40] global model row
+ *             (device/HitReporting.cpp:421-430; decoded at host/Havac.cpp:155-163),
+ *             returned in the FPGA's emission order: segment ascending, then row
+ *             ascending, then column ascending (device/HavacHls.cpp:151-152,264).
+ *
+ * Every function returns HAVAC_OK (0) or a negative HAVAC_E_* code; the text
+ * of the last failure on a handle is available from havac_dev_last_error().
+ * A handle is not thread-safe (neither is HavacHwClient).
+ */
+#ifndef HAVAC_DEV_H
+#define HAVAC_DEV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAVAC_SEGMENT_COLUMNS 12288u /* device/PublicDefines.h:18-22 */
+
+/* error codes; the C++ `Havac` wrapper maps them back to the exception types
+ * the reference throws (noted per code) */
+enum {
+    HAVAC_OK = 0,
+    HAVAC_E_LENGTH = -1,       /* std::length_error  host/HavacHwClient.cpp:88,96,118,124,143,146 */
+    HAVAC_E_LOGIC = -2,        /* std::logic_error   host/HavacHwClient.cpp:168, host/Havac.cpp:86-91 */
+    HAVAC_E_RUNTIME = -3,      /* std::runtime_error host/HavacHwClient.cpp:179,182 and HIP failures */
+    HAVAC_E_NOMEM = -4,        /* std::bad_alloc */
+    HAVAC_E_HIT_OVERFLOW = -5, /* more hits than the hit buffer holds (the reference has a fixed 3.5 GiB
+                                  buffer and no check, host/HavacHwClient.hpp:94) */
+    HAVAC_E_NO_DEVICE = -6,    /* no usable gfx950 device / HIP runtime */
+    HAVAC_E_ARGUMENT = -7
+};
+
+/* run states, numerically equal to havac_cmd_state / ert_cmd_state
+ * (host/Havac.hpp:16-26) */
+enum {
+    HAVAC_STATE_NEW = 1,
+    HAVAC_STATE_QUEUED = 2,
+    HAVAC_STATE_RUNNING = 3,
+    HAVAC_STATE_COMPLETED = 4,
+    HAVAC_STATE_ERROR = 5,
+    HAVAC_STATE_ABORT = 6,
+    HAVAC_STATE_SUBMITTED = 7,
+    HAVAC_STATE_TIMEOUT = 8,
+    HAVAC_STATE_NORESPONSE = 9
+};
+
+/* ------------------------------------------------------------------------
+ * Level 1: handle API (replaces class HavacHwClient)
+ * ---------------------------------------------------------------------- */
+typedef struct havac_dev havac_dev;
+
+/* HavacHwClient::HavacHwClient(xclbin, kernelName, deviceIndex)
+ * host/HavacHwClient.cpp:25-31.  There is no bitstream to load; the kernels
+ * are inside the library.  Allocates the hit buffer (default capacity
+ * 16 Mi records; see havac_dev_set_hit_capacity). */
+int havac_dev_create(uint32_t device_index, havac_dev **out);
+void havac_dev_destroy(havac_dev *dev);
+
+/* Hit-buffer capacity in records; the reference's fixed value is
+ * 14*256 MiB / 8 = 469,762,048 (host/HavacHwClient.hpp:94). */
+int havac_dev_set_hit_capacity(havac_dev *dev, uint64_t max_hits);
+
+/* HavacHwClient::writeSequence  host/HavacHwClient.cpp:78-110.
+ * Borrowed host pointer, copied to HBM before return. */
+int havac_dev_write_sequence(havac_dev *dev, const uint8_t *packed2bit, uint64_t nbytes);
+
+/* HavacHwClient::writePhmm  host/HavacHwClient.cpp:111-138. */
+int havac_dev_write_phmm(havac_dev *dev, const int8_t *scores, uint64_t nbytes);
+
+/* HavacHwClient::invokeHavacSsvAsync  host/HavacHwClient.cpp:141-151.
+ * Enqueues on the handle's private stream and returns. */
+int havac_dev_run_async(havac_dev *dev);
+
+/* HavacHwClient::getHwState  host/HavacHwClient.cpp:163-170.
+ * Returns a HAVAC_STATE_* value (>0) or a negative error (LOGIC when no run
+ * was ever started, as the reference throws). */
+int havac_dev_state(havac_dev *dev);
+
+/* HavacHwClient::waitForHavacSsvAsync  host/HavacHwClient.cpp:153-157.
+ * timeout_ms == 0 waits without limit (xrt::run::wait semantics).  Returns the
+ * state on return: COMPLETED, TIMEOUT, ABORT or ERROR. */
+int havac_dev_wait(havac_dev *dev, uint32_t timeout_ms);
+
+/* HavacHwClient::abort  host/HavacHwClient.cpp:159-161.  Raises a flag the
+ * kernel polls between row chunks, then waits for the stream to drain.
+ * Returns HAVAC_STATE_ABORT, or COMPLETED if the run had already finished. */
+int havac_dev_abort(havac_dev *dev);
+
+/* HavacHwClient::getNumHits / getHitList  host/HavacHwClient.cpp:172-202.
+ * Valid after a completed run.  read_hits copies min(n, count) records in
+ * device order. */
+int havac_dev_num_hits(havac_dev *dev, uint32_t *count);
+int havac_dev_read_hits(havac_dev *dev, uint64_t *out, uint32_t n);
+
+/* Device time of the last completed run in milliseconds (HIP events on the
+ * handle's stream): the SSV kernel alone, and the whole enqueue (model
+ * expansion + SSV + hit ordering). */
+int havac_dev_last_run_ms(havac_dev *dev, float *ssv_kernel_ms, float *total_ms);
+
+const char *havac_dev_last_error(havac_dev *dev);
+
+/* ------------------------------------------------------------------------
+ * Level 2: kernel ABI on caller-owned device memory (replaces HavacKernel)
+ * ---------------------------------------------------------------------- */
+typedef struct havac_ssv_ctx havac_ssv_ctx;
+
+/* A context belongs to the HIP device that is current when it is created.  It
+ * caches the scratch the launch needs (the expanded model and the sort's
+ * temporary storage), so steady-state launches allocate nothing. */
+int havac_ssv_ctx_create(havac_ssv_ctx **out);
+void havac_ssv_ctx_destroy(havac_ssv_ctx *ctx);
+
+/* Enqueue one SSV pass on `hip_stream` (a hipStream_t passed as void*; NULL is
+ * the default stream) and return without waiting.  All pointers are DEVICE
+ * pointers.
+ *
+ *   d_sequence   2-bit packed sequence, 8-byte aligned, nsymbols % 12288 == 0
+ *   d_phmm       int8 [nrows][4], 4-byte aligned
+ *   shard_index, shard_count
+ *                the DP matrix is cut along its diagonals into shard_count
+ *                pieces of nearly equal work and only piece shard_index is
+ *                computed (a cell depends on its own diagonal only, so no halo
+ *                is recomputed and the union over shards is the whole answer);
+ *                0,1 computes everything
+ *   d_hits       receives up to hit_capacity records
+ *   d_abort_flag optional uint32 the kernel polls; nonzero stops the run
+ *
+ * Mirrors HavacKernel(sequenceSegmentMemory, sequenceLengthInSegments,
+ * phmmVectorMemory, phmmLengthInVectors, hitReportMemory, hitReportCountMemory)
+ * at device/HavacHls.cpp:20-43; the hit count is returned by havac_ssv_finish. */
+int havac_ssv_enqueue(havac_ssv_ctx *ctx, const uint8_t *d_sequence, uint64_t nsymbols,
+                      const int8_t *d_phmm, uint32_t nrows, uint32_t shard_index,
+                      uint32_t shard_count, uint64_t *d_hits, uint64_t hit_capacity,
+                      const uint32_t *d_abort_flag, void *hip_stream);
+
+/* Completes the enqueued pass: waits for it, puts the shard's records in
+ * d_hits into device order (radix sort on the same stream) and returns the
+ * number of hits found.  If that exceeds hit_capacity only hit_capacity
+ * records were kept and the result is HAVAC_E_HIT_OVERFLOW. */
+int havac_ssv_finish(havac_ssv_ctx *ctx, uint64_t *hit_count_out);
+
+/* Sort `count` packed records in place into device order (used by rank 0 after
+ * gathering the shards' hit lists). */
+int havac_ssv_sort_hits(havac_ssv_ctx *ctx, uint64_t *d_hits, uint64_t count, void *hip_stream);
+
+/* After the stream has been synchronised: device time of the last enqueue's
+ * SSV kernel and of the whole enqueue, from HIP events recorded on that stream. */
+int havac_ssv_last_ms(havac_ssv_ctx *ctx, float *ssv_kernel_ms, float *total_ms);
+
+/* Number of DP cells the given shard updates (defined cells only: padding
+ * rows/diagonals outside the matrix are not counted), for GCUPS accounting. */
+uint64_t havac_ssv_shard_cells(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index,
+                               uint32_t shard_count);
+
+const char *havac_ssv_ctx_last_error(havac_ssv_ctx *ctx);
+
+/* Library self-description, e.g. "havac_dev 0.1 gfx950". */
+const char *havac_dev_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
