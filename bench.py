@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- GCUPS of the SSV hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A step is one whole pass of the hot path over one batch of synthetic input that
+is already resident in HBM: model expansion + SSV kernel + hit compaction +
+ordering of the hit records into the reference's device order (+ for N > 1 the
+RCCL gather of the records to rank 0 and the final ordering there).
+
+Workload at N = 1 is BASELINE.json configs[1] ("C2"): one pHMM of L = 1024 rows x
+100 Mbp of synthetic sequence (100,012,032 columns after padding to 12288),
+int8 scores, one kernel launch.  For N > 1 the run is WEAK-scaled: the database
+grows to N x 100,012,032 columns and is cut along its diagonals into N shards,
+one per rank (havac_amd/dist.py); every rank holds the whole packed sequence
+(N x 25 MB) in its own HBM, so no data-path collective is needed.
+
+GCUPS = defined DP cells (columns x rows; padding outside the matrix is not
+counted) / wall time of the K timed steps, max over ranks.
+
+One JSON line is printed by rank 0; see README/DESIGN.md for the extra objects
+`roofline` (integer-VALU bound, with the HBM figures next to it) and
+`cpu_baseline` (the reference's softSsv, or our C restatement of it, on the
+host cores, on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from havac_amd import synth  # noqa: E402
+
+COLUMNS_PER_GPU = 100_012_032          # 100 Mbp padded to 12288 (8139 segments)
+ROWS = 1024
+FPGA_GCUPS = 1739.0                    # reference README.md:4 (Alveo U50), BASELINE.md section 1
+
+# MI355X integer-VALU peak: 256 CUs x 4 SIMD x 32 lanes/clk x 2.4 GHz = 78.6e12 32-bit lane-ops/s
+# (= the 157.3 TFLOP/s fp32 vector peak / 2 flop per FMA, MI355X_MICROARCH.md chip table); every
+# lane-op carries two int16 operations in packed form -> 157.3e12 int16 ops/s.
+PEAK_TIOPS_I16 = 157.3
+OPS_PER_CELL = 2                       # one 4:1 score select + one saturating add
+HBM_PEAK_GBS = 8000.0
+
+
+def plant_packed(packed: np.ndarray, consensus: np.ndarray, nreal: int, every=1_000_000, length=300, sub=0.15,
+                 seed=synth.SEED_PLANT) -> int:
+    """synth.plant_homologs on a 2-bit packed buffer (only the touched bytes are unpacked)."""
+    rng = np.random.default_rng(seed)
+    length = min(length, consensus.size)
+    planted, pos = 0, every // 2
+    while pos + length <= nreal:
+        start = int(rng.integers(0, consensus.size - length + 1))
+        piece = consensus[start:start + length].copy()
+        mut = rng.random(length) < sub
+        piece[mut] = rng.integers(0, 4, size=int(mut.sum()), dtype=np.uint8)
+        b0, b1 = pos // 4, (pos + length + 3) // 4
+        sym = synth.unpack_2bit(packed[b0:b1])
+        sym[pos - 4 * b0: pos - 4 * b0 + length] = piece
+        packed[b0:b1] = synth.pack_2bit(sym)
+        planted += 1
+        pos += every
+    return planted
+
+
+def cpu_baseline(packed: np.ndarray, model: np.ndarray, gpu_hits: np.ndarray, cores: int, cols_per_core: int):
+    """Time the CPU path on a bounded sample (the first cores*cols_per_core columns, all rows) and
+    check that it finds exactly the hits the GPU reported for those columns."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle as O
+    nrows = model.shape[0]
+    sample_cols = min(cores * cols_per_core, packed.size * 4)
+    sample_cols -= sample_cols % 4
+    sym = synth.unpack_2bit(packed[: sample_cols // 4])
+    use_ref = O.ref_available()
+    blocks = [(k * cols_per_core, min((k + 1) * cols_per_core, sample_cols)) for k in range(cores)]
+    blocks = [b for b in blocks if b[0] < b[1]]
+
+    def one(block):
+        a, b = block
+        start = max(0, a - (nrows - 1))
+        if use_ref:     # the reference's own softSsvThreshold256 on [start, b), hits left of `a` dropped
+            h = O.ssv_reference(sym[start:b], model)
+            rows, cols = O.unpack_hits(h)
+            cols = cols + np.uint64(start)
+            keep = cols >= np.uint64(a)
+            return O.pack_hits(rows[keep], cols[keep])
+        return O.ssv_window(sym, model, a, b)
+
+    O.lib()
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=len(blocks)) as pool:
+        parts = list(pool.map(one, blocks))
+    dt = time.perf_counter() - t0
+    cpu_hits = O.device_order(np.concatenate(parts)) if parts else np.zeros(0, np.uint64)
+    _, gcols = O.unpack_hits(gpu_hits)
+    match = bool(np.array_equal(cpu_hits, O.device_order(gpu_hits[gcols < np.uint64(sample_cols)])))
+    cells = sample_cols * nrows
+    return {
+        "value": round(cells / dt / 1e9, 4), "unit": "GCUPS", "cores": len(blocks),
+        "kind": "reference" if use_ref else "port",
+        "sample": f"first {sample_cols} columns x {nrows} rows of the same workload ({cells:.3g} cells, {dt:.1f} s wall, "
+                  f"{len(blocks)} threads each a column block with a {nrows - 1}-column left halo)",
+        "hits_match_gpu": match, "hits_in_sample": int(cpu_hits.size),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=ROWS)
+    ap.add_argument("--columns-per-gpu", type=int, default=COLUMNS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cols-per-core", type=int, default=300_000)
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch of the SSV kernel from a separate rocprofv3 --pmc pass (profiles/)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from havac_amd.dist import ShardedSsv
+    from havac_amd.ssv import shard_cells
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    assert args.columns_per_gpu % synth.SEGMENT == 0
+    ncols = args.columns_per_gpu * world
+    nrows = args.rows
+
+    # ---- synthetic inputs (same on every rank: same seeds) -------------------
+    model, consensus = synth.dfam_like_model(nrows, synth.SEED_MODEL)
+    packed = synth.random_packed(ncols, synth.SEED_SEQUENCE)
+    nreal = ncols - 12_032 * world if args.columns_per_gpu == COLUMNS_PER_GPU else ncols
+    planted = plant_packed(packed, consensus, nreal)
+    packed[nreal // 4:] = 0                      # padding is symbol 0 ('A'), SequencePreprocessor.cpp:41
+    d_seq = torch.from_numpy(packed).to(device)
+    d_phmm = torch.from_numpy(model.reshape(-1)).to(device)
+
+    hit_capacity = max(1 << 20, int(args.columns_per_gpu * nrows * 4e-5))
+    engine = ShardedSsv(hit_capacity, device)
+    my_cells = shard_cells(ncols, nrows, rank, world)
+    total_cells = ncols * nrows
+
+    def step():
+        return engine.run(d_seq, ncols, d_phmm, nrows)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        merged, found = step()
+        kernel_ms.append(engine.ctx.last_ms())
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        gcups = total_cells / (elapsed / args.steps) / 1e9
+        ssv_ms = float(np.mean([k[0] for k in kernel_ms]))
+        enq_ms = float(np.mean([k[1] for k in kernel_ms]))
+        nhits = int(merged.numel())
+        hits_np = merged.cpu().numpy().view(np.uint64)
+        # algorithmic HBM bytes of this rank's launch: its share of the packed sequence once, the
+        # widened model once (8 B/row), 8 B per hit
+        algo_bytes = ncols / 4 / world + 8 * nrows + 8 * found
+        kernel_s = ssv_ms / 1e3
+        achieved_tiops = my_cells * OPS_PER_CELL / kernel_s / 1e12
+        out = {
+            "metric": "GCUPS (billion SSV cells/s); hit-list bit-exact vs softSsv",
+            "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": round(gcups / FPGA_GCUPS, 3), "dtype": "i16 (packed pairs over int8 scores)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2: 1 pHMM L={nrows} x {args.columns_per_gpu} columns per GPU (100 Mbp padded to 12288), "
+                            "int8 SSV, one kernel launch per step",
+                "rows": nrows, "columns": ncols, "cells_per_step": total_cells, "hits_per_step": nhits,
+                "planted_homologs": planted,
+                "parallelism": f"diagonal-sharded x{world}" + (", RCCL all_gather of hit records" if world > 1 else ""),
+                "baseline": "1739 GCUPS = reference README.md:4, 1x Alveo U50 FPGA",
+            },
+            "kernel": {"name": "ssv_diag_kernel", "avg_ms": round(ssv_ms, 4), "enqueue_to_ordered_ms": round(enq_ms, 4),
+                       "gcups_kernel_only": round(my_cells / kernel_s / 1e9, 1)},
+            "roofline": {
+                "bound": "valu", "achieved": round(achieved_tiops, 2), "peak": PEAK_TIOPS_I16,
+                "unit": "Tiop/s (int16 ops; 2 per cell)", "frac": round(achieved_tiops / PEAK_TIOPS_I16, 4),
+                "traffic": args.traffic_bytes,
+                "hbm": {"bound": "hbm", "achieved": round(algo_bytes / kernel_s / 1e9, 3), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(algo_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, 6),
+                        "algorithmic_bytes_per_launch": int(algo_bytes)},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cores = min(16, len(os.sched_getaffinity(0)))   # a 1-GPU box's CPU share
+            out["cpu_baseline"] = cpu_baseline(packed, model, hits_np, cores, args.cpu_cols_per_core)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

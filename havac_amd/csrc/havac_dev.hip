@@ -163,6 +163,18 @@ extern "C" uint64_t havac_ssv_shard_cells(uint64_t nsymbols, uint32_t nrows, uin
     return cells_below_diag(nsymbols, nrows, D1) - cells_below_diag(nsymbols, nrows, D0);
 }
 
+extern "C" int havac_ssv_shard_diagonals(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index,
+                                         uint32_t shard_count, int64_t* diag_begin, int64_t* diag_end) {
+    if (!diag_begin || !diag_end || shard_count == 0 || shard_index >= shard_count || nrows == 0 || nsymbols == 0)
+        return HAVAC_E_ARGUMENT;
+    Tiling t = make_tiling(nsymbols, nrows);
+    uint32_t b, e;
+    shard_tiles(t, nsymbols, shard_index, shard_count, &b, &e);
+    *diag_begin = t.first_diag + (int64_t)b * kTileDiags;
+    *diag_end = t.first_diag + (int64_t)e * kTileDiags;
+    return HAVAC_OK;
+}
+
 static int check_inputs(std::string& err, uint64_t nsymbols, uint32_t nrows) {
     // host/HavacHwClient.cpp:81-97,112-125,142-147; device/HavacHls.hpp:19-20
     if (nsymbols == 0) { err = "sequence length in segments cannot be 0, but 0 was given to the client."; return HAVAC_E_LENGTH; }

@@ -115,16 +115,67 @@ __device__ __forceinline__ uint2 load_symbols(const uint8_t* __restrict__ seq, i
     return *reinterpret_cast<const uint2*>(seq + (pos >> 2));
 }
 
-// Slow path, reached only by waves that saw bit 8 in some score this row.
-// One bit per diagonal of this lane; the column of bit b is column0 + b.
-__device__ __noinline__ void emit_hits(uint64_t* __restrict__ hits, unsigned long long* __restrict__ hit_count,
-                                       uint64_t hit_capacity, uint32_t mask, uint32_t row, int64_t column0) {
-    while (mask) {
-        int b = __builtin_ctz(mask);
-        mask &= mask - 1;
-        unsigned long long idx = atomicAdd(hit_count, 1ull);
-        if (idx < hit_capacity) hits[idx] = hit_key(row, (uint64_t)(column0 + b));
+// ---- hit queue --------------------------------------------------------------
+// Counterpart of the FPGA's five-stage hit sieve (device/HitReporting.cpp:12-417).
+// Hot loop: the 16 score registers of a row are OR-ed and one wave-wide test
+// looks for bit 8.  Only a wave that sees it runs the per-row slow path, which
+// turns the crossings into one 32-bit mask per lane (bit b = diagonal b of the
+// lane), resets those cells to 0 and parks the mask in LDS.  Once per 32-row
+// chunk the parked masks are turned into records, staged in the wave's LDS
+// slice and appended to the global queue in bursts: one returning atomic per
+// burst instead of one per hit (a single counter word sustains only ~90
+// returning atomics per microsecond chip-wide, which capped the first version
+// of this kernel at ~90 M hits/s).
+constexpr int kHitStage = 128;                    // records staged per wave (1 KiB of LDS)
+
+struct HitSink {
+    uint64_t* hits;                // global queue of sort keys (hit_key)
+    unsigned long long* hit_count; // records found so far (may run past capacity)
+    uint64_t hit_capacity;
+    uint64_t* stage;               // this wave's LDS slice, kHitStage records
+    uint32_t* row_masks;           // this wave's LDS slice, kChunkRows x 64 masks
+};
+
+__device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t staged, int lane) {
+    if (staged == 0) return 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(sink.hit_count, (unsigned long long)staged);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    base = ((unsigned long long)hi << 32) | lo;
+    for (uint32_t i = lane; i < staged; i += 64) {
+        const unsigned long long idx = base + i;
+        if (idx < sink.hit_capacity) sink.hits[idx] = sink.stage[i];
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return 0;
+}
+
+// Once per chunk, only if some row of the chunk parked masks.  `rows_with_hits`
+// has bit r set for row p0 + r.  The column of bit b of lane l on row p0 + r is
+// wave_column0 + r + 32*l + b.  Returns the new number of staged records.
+__device__ __noinline__ uint32_t drain_rows(const HitSink sink, uint32_t staged, uint32_t rows_with_hits, uint32_t p0,
+                                            int64_t wave_column0, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    while (rows_with_hits) {
+        const int r = __builtin_ctz(rows_with_hits);
+        rows_with_hits &= rows_with_hits - 1;
+        const uint32_t mask = sink.row_masks[r * 64 + lane];
+        unsigned long long lanes = __ballot(mask != 0);
+        while (lanes) {
+            const int src = __builtin_ctzll(lanes);
+            lanes &= lanes - 1;
+            const uint32_t m = __builtin_amdgcn_readlane(mask, src);
+            if (lane < 32 && ((m >> lane) & 1u)) {
+                const uint32_t pos = staged + __popc(m & ((1u << lane) - 1u));
+                sink.stage[pos] = hit_key(p0 + r, (uint64_t)(wave_column0 + r + 32 * src + lane));
+            }
+            staged += __popc(m);
+            if (staged > kHitStage - 32) staged = flush_hits(sink, staged, lane);
+        }
+    }
+    return staged;
 }
 
 // The expanded model is read through the constant address space: the address
@@ -133,18 +184,13 @@ __device__ __noinline__ void emit_hits(uint64_t* __restrict__ hits, unsigned lon
 typedef uint32_t row16_t __attribute__((ext_vector_type(2)));   // {A,C} , {G,T} as int16 pairs
 typedef const __attribute__((address_space(4))) row16_t* const_rows_t;
 
-struct HitSink {
-    uint64_t* hits;
-    unsigned long long* hit_count;
-    uint64_t hit_capacity;
-};
-
 // One model row over the lane's 32 diagonals.  R is the row inside the chunk:
 // a template parameter so that every selector index is a compile-time constant
 // and the sliding symbol window costs no instruction.
 template <int R>
 __device__ __forceinline__ void row_step(uint32_t (&x)[kRegs], const uint32_t (&W)[32], const uint32_t (&Wodd)[31],
-                                         const row16_t row, const HitSink& sink, uint32_t p0, int64_t column0) {
+                                         const row16_t row, uint32_t* __restrict__ row_masks, uint32_t& rows_with_hits,
+                                         int lane) {
     uint32_t any = 0;
 #pragma unroll
     for (int i = 0; i < kRegs; i++) {
@@ -157,24 +203,21 @@ __device__ __forceinline__ void row_step(uint32_t (&x)[kRegs], const uint32_t (&
         uint32_t mask = 0;
 #pragma unroll
         for (int i = 0; i < kRegs; i++) {
-            const uint32_t h = x[i] & kHitBits;
-            if (h & 0x100u) { mask |= 1u << (2 * i); x[i] = (x[i] & 0xffff0000u) | 0x8000u; }
-            if (h & 0x1000000u) { mask |= 2u << (2 * i); x[i] = (x[i] & 0x0000ffffu) | 0x80000000u; }
+            const uint32_t h = (x[i] >> 8) & 0x00010001u;              // bit 0 / bit 16: low / high cell crossed 256
+            mask |= ((h | (h >> 15)) & 3u) << (2 * i);
+            const uint32_t sel16 = h * 0xffffu;                       // 0xffff over each crossed cell
+            x[i] = (x[i] & ~sel16) | (kScoreZero & sel16);             // crossed cells restart at 0 (SoftSsv.cpp:43-44)
         }
-        if (mask) emit_hits(sink.hits, sink.hit_count, sink.hit_capacity, mask, p0 + R, column0 + R);
+        row_masks[R * 64 + lane] = mask;
+        rows_with_hits |= 1u << R;
     }
 }
 
 template <int... R>
 __device__ __forceinline__ void chunk_rows(uint32_t (&x)[kRegs], const uint32_t (&W)[32], const uint32_t (&Wodd)[31],
-                                           const_rows_t rows, const HitSink& sink, uint32_t p0,
-                                           int64_t column0, std::integer_sequence<int, R...>) {
-    // all rows of the chunk are fetched up front (one batch of scalar loads, one wait) rather than
-    // one dependent s_load per row
-    row16_t row[kChunkRows];
-#pragma unroll
-    for (int r = 0; r < kChunkRows; r++) row[r] = rows[r];
-    (row_step<R>(x, W, Wodd, row[R], sink, p0, column0), ...);
+                                           const row16_t (&row)[kChunkRows], uint32_t* __restrict__ row_masks,
+                                           uint32_t& rows_with_hits, int lane, std::integer_sequence<int, R...>) {
+    (row_step<R>(x, W, Wodd, row[R], row_masks, rows_with_hits, lane), ...);
 }
 
 __global__ __launch_bounds__(64 * kWavesPerBlock)
@@ -182,13 +225,17 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
                      const uint32_t nrows_padded, const int64_t first_diag, const uint32_t tile_begin,
                      const uint32_t tile_end, uint64_t* __restrict__ hits, unsigned long long* __restrict__ hit_count,
                      const uint64_t hit_capacity, const uint32_t* __restrict__ abort_flag) {
+    __shared__ uint64_t hit_stage[kWavesPerBlock][kHitStage];
+    __shared__ uint32_t hit_masks[kWavesPerBlock][kChunkRows * 64];
+
     const int lane = threadIdx.x & 63;
     // readfirstlane: everything derived from the tile index is wave-uniform, which lets hipcc keep
     // the row pointer in SGPRs (scalar loads of the model rows) and branch on `edge` with SALU
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t tile = tile_begin + blockIdx.x * kWavesPerBlock + wave;
     if (tile >= tile_end) return;
-    const HitSink sink{hits, hit_count, hit_capacity};
+    const HitSink sink{hits, hit_count, hit_capacity, hit_stage[wave], hit_masks[wave]};
+    uint32_t staged = 0;          // wave-uniform
 
     const int64_t d0 = first_diag + (int64_t)tile * kTileDiags;     // wave's first diagonal
     const int64_t dl = d0 + lane * kDiagsPerLane;                   // lane's first diagonal
@@ -209,7 +256,13 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
 
     for (int64_t p0 = p_lo; p0 < p_hi; p0 += kChunkRows) {
         if (abort_flag && ((p0 & 2047) == 0) &&
-            __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+            __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+        // all rows of the chunk are fetched up front (one batch of scalar loads, one wait)
+        const const_rows_t rows = (const_rows_t)(const row16_t*)(rows16 + p0);
+        row16_t row[kChunkRows];
+#pragma unroll
+        for (int r = 0; r < kChunkRows / 2; r++) row[r] = rows[r];
+
         const int64_t j = dl + p0;
         edge = (d0 + p0 < 0) || (d0 + p0 + kTileDiags + kChunkRows > nsymbols);
         const uint2 lo = hi;
@@ -238,9 +291,14 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
             asm volatile("" : "+v"(Wodd[k]));   // keep it in a VGPR: hipcc otherwise recomputes it in every odd row
         }
 
-        chunk_rows(x, W, Wodd, (const_rows_t)(const row16_t*)(rows16 + p0), sink, (uint32_t)p0, dl + p0,
-                   std::make_integer_sequence<int, kChunkRows>{});
+#pragma unroll
+        for (int r = kChunkRows / 2; r < kChunkRows; r++) row[r] = rows[r];   // lands while rows 0..15 run
+
+        uint32_t rows_with_hits = 0;   // wave-uniform
+        chunk_rows(x, W, Wodd, row, sink.row_masks, rows_with_hits, lane, std::make_integer_sequence<int, kChunkRows>{});
+        if (rows_with_hits) staged = drain_rows(sink, staged, rows_with_hits, (uint32_t)p0, d0 + p0, lane);
     }
+    flush_hits(sink, staged, lane);
 }
 
 // ---------------------------------------------------------------------------

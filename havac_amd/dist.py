@@ -1,0 +1,62 @@
+"""Multi-GPU SSV: one process per GPU, the DP matrix cut along its diagonals.
+
+A cell depends only on its own diagonal, so rank r
+computes shard r of `world_size` with no halo recomputation and no data-path
+collective.  The only exchange is the gather of each rank's packed hit records
+to rank 0 at the end (RCCL over xGMI when the backend is "nccl"; the same code
+runs over gloo on CPU tensors in the tests).  The reference has no multi-device
+path at all (host/Havac.hpp:51: one deviceIndex per object).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def gather_hits(local_hits: torch.Tensor, local_count: int, group=None):
+    """All ranks call this with their own records (int64 view of the packed u64, first
+    `local_count` valid).  Returns (concatenated records, per-rank counts) on rank 0 and
+    (None, counts) elsewhere.  Two collectives: an all_gather of the counts, then an
+    all_gather of the records padded to the largest count (payload is KB..MB)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = local_hits.device
+    mine = torch.tensor([local_count], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, mine, group=group)
+    counts = [int(c.item()) for c in counts]
+    biggest = max(counts)
+    if biggest == 0:
+        return (local_hits[:0].clone() if rank == 0 else None), counts
+    padded = torch.zeros(biggest, dtype=local_hits.dtype, device=dev)
+    padded[:local_count] = local_hits[:local_count]
+    parts = [torch.empty(biggest, dtype=local_hits.dtype, device=dev) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    if rank != 0:
+        return None, counts
+    return torch.cat([p[:c] for p, c in zip(parts, counts)]), counts
+
+
+class ShardedSsv:
+    """Rank-local driver: enqueue this rank's shard, order its hits, gather to rank 0, order the union."""
+
+    def __init__(self, hit_capacity: int, device: torch.device):
+        from .ssv import SsvContext
+        self.ctx = SsvContext()
+        self.device = device
+        self.hits = torch.empty(hit_capacity, dtype=torch.int64, device=device)
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def run(self, d_seq: torch.Tensor, nsymbols: int, d_phmm: torch.Tensor, nrows: int):
+        """-> (records on rank 0 in device order or None, hits found by this rank)"""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.ctx.enqueue(d_seq.data_ptr(), nsymbols, d_phmm.data_ptr(), nrows, self.hits.data_ptr(),
+                         self.hits.numel(), self.rank, self.world, 0, stream)
+        found = self.ctx.finish()
+        if self.world == 1:
+            return self.hits[:found], found
+        merged, _ = gather_hits(self.hits, found)
+        if merged is not None and merged.numel() > 1:
+            self.ctx.sort_hits(merged.data_ptr(), merged.numel(), stream)
+        return merged, found

@@ -1,0 +1,63 @@
+"""Kernel-ABI wrapper (level 2 of include/havac_dev.h): SSV on caller-owned device memory.
+
+Takes raw device addresses (ints) and a raw HIP stream handle so that it stays
+independent of torch; bench.py and havac_amd/dist.py pass `tensor.data_ptr()`
+and `torch.cuda.current_stream().cuda_stream`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import _lib
+from .hw_client import raise_for
+
+
+class SsvContext:
+    def __init__(self):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        rc = self._L.havac_ssv_ctx_create(C.byref(h))
+        if rc != 0:
+            raise_for(rc, "could not create an SSV context (no gfx950 device?)")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.havac_ssv_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise_for(rc, (self._L.havac_ssv_ctx_last_error(self._h) or b"").decode())
+
+    def enqueue(self, d_sequence: int, nsymbols: int, d_phmm: int, nrows: int, d_hits: int, hit_capacity: int,
+                shard_index: int = 0, shard_count: int = 1, d_abort_flag: int = 0, stream: int = 0):
+        self._check(self._L.havac_ssv_enqueue(self._h, d_sequence, nsymbols, d_phmm, nrows, shard_index, shard_count,
+                                              d_hits, hit_capacity, d_abort_flag or None, stream or None))
+
+    def finish(self) -> int:
+        n = C.c_uint64(0)
+        self._check(self._L.havac_ssv_finish(self._h, C.byref(n)))
+        return n.value
+
+    def sort_hits(self, d_hits: int, count: int, stream: int = 0):
+        self._check(self._L.havac_ssv_sort_hits(self._h, d_hits, count, stream or None))
+
+    def last_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(self._L.havac_ssv_last_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+def shard_cells(nsymbols: int, nrows: int, shard_index: int = 0, shard_count: int = 1) -> int:
+    return int(_lib.load().havac_ssv_shard_cells(nsymbols, nrows, shard_index, shard_count))
+
+
+def shard_diagonals(nsymbols: int, nrows: int, shard_index: int, shard_count: int):
+    b, e = C.c_int64(0), C.c_int64(0)
+    rc = _lib.load().havac_ssv_shard_diagonals(nsymbols, nrows, shard_index, shard_count, C.byref(b), C.byref(e))
+    if rc != 0:
+        raise_for(rc, "bad shard arguments")
+    return b.value, e.value

@@ -186,6 +186,12 @@ int havac_ssv_last_ms(havac_ssv_ctx *ctx, float *ssv_kernel_ms, float *total_ms)
 uint64_t havac_ssv_shard_cells(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index,
                                uint32_t shard_count);
 
+/* The half-open range of diagonals (column - row) shard `shard_index` owns.
+ * Host-only arithmetic (no device needed): lets a caller predict which hits a
+ * shard will report. */
+int havac_ssv_shard_diagonals(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index,
+                              uint32_t shard_count, int64_t *diag_begin, int64_t *diag_end);
+
 const char *havac_ssv_ctx_last_error(havac_ssv_ctx *ctx);
 
 /* Library self-description, e.g. "havac_dev 0.1 gfx950". */
