@@ -42,12 +42,21 @@ COLUMNS_PER_GPU = 100_012_032          # 100 Mbp padded to 12288 (8139 segments)
 ROWS = 1024
 FPGA_GCUPS = 1739.0                    # reference README.md:4 (Alveo U50), BASELINE.md section 1
 
-# MI355X integer-VALU peak: 256 CUs x 4 SIMD x 32 lanes/clk x 2.4 GHz = 78.6e12 32-bit lane-ops/s
-# (= the 157.3 TFLOP/s fp32 vector peak / 2 flop per FMA, MI355X_MICROARCH.md chip table); every
-# lane-op carries two int16 operations in packed form -> 157.3e12 int16 ops/s.
-PEAK_TIOPS_I16 = 157.3
+# Integer-VALU roofline.  The two instructions the recurrence needs -- the byte select v_perm_b32 and
+# the packed saturating add v_pk_add_i16 -- belong to gfx950's HALF-rate VALU class: a wave64
+# instruction holds its SIMD for 4 cycles (16 lanes/clk), measured with tools/valu_rates.hip
+# (profiles/r01_valu_rates_4waves_per_simd.txt; the full-rate class, 2 cycles, is v_add_u32 / v_and /
+# v_fma_f32 ... and has no byte permute or packed saturating add).  Peak for this class:
+# 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3e12 lane-ops/s (the figure SURVEY.md 8d uses),
+# x 2 int16 operations per packed lane-op = 78.6e12 int16 ops/s.
+PEAK_TIOPS_I16 = 78.6
+PEAK_TIOPS_I16_FULL_RATE_CLASS = 157.3  # what the same count would be against 32 lanes/clk (fp32-FMA class)
 OPS_PER_CELL = 2                       # one 4:1 score select + one saturating add
 HBM_PEAK_GBS = 8000.0
+# HBM bytes per launch of ssv_diag_kernel on the default workload, from the separate rocprofv3 --pmc
+# passes in profiles/r01_pmc_c2.csv: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 with the gfx950 FETCH_SIZE
+# correction of MI355X_MICROARCH.md (uncalibrated for 8-byte-per-lane loads: an upper bound).
+PMC_TRAFFIC_C2_BYTES = (2 * 14162.1 + 10146.3) * 1024
 
 
 def plant_packed(packed: np.ndarray, consensus: np.ndarray, nreal: int, every=1_000_000, length=300, sub=0.15,
@@ -218,7 +227,9 @@ def main():
             "roofline": {
                 "bound": "valu", "achieved": round(achieved_tiops, 2), "peak": PEAK_TIOPS_I16,
                 "unit": "Tiop/s (int16 ops; 2 per cell)", "frac": round(achieved_tiops / PEAK_TIOPS_I16, 4),
-                "traffic": args.traffic_bytes,
+                "frac_vs_full_rate_class_peak": round(achieved_tiops / PEAK_TIOPS_I16_FULL_RATE_CLASS, 4),
+                "traffic": args.traffic_bytes if args.traffic_bytes is not None else (
+                    PMC_TRAFFIC_C2_BYTES if (world == 1 and nrows == ROWS and args.columns_per_gpu == COLUMNS_PER_GPU) else None),
                 "hbm": {"bound": "hbm", "achieved": round(algo_bytes / kernel_s / 1e9, 3), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(algo_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, 6),
                         "algorithmic_bytes_per_launch": int(algo_bytes)},
