@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--columns-per-gpu", type=int, default=COLUMNS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cols-per-core", type=int, default=300_000)
+    ap.add_argument("--cpu-cols-per-core", type=int, default=500_000)
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the SSV kernel from a separate rocprofv3 --pmc pass (profiles/)")
     args = ap.parse_args()

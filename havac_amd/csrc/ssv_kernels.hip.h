@@ -220,6 +220,14 @@ __device__ __forceinline__ void chunk_rows(uint32_t (&x)[kRegs], const uint32_t 
     (row_step<R>(x, W, Wodd, row[R], row_masks, rows_with_hits, lane), ...);
 }
 
+// Selector words of the 4 symbols of one packed byte, through a 256-entry LDS
+// table (2 KiB per workgroup, built once): two words per ds_read_b64 instead
+// of ten VALU instructions.
+__device__ __forceinline__ uint2 byte_selectors(const uint2* __restrict__ lut, uint32_t w, int byte) {
+    const uint32_t off = (byte == 0 ? (w << 3) : (w >> (8 * byte - 3))) & 0x7f8u;   // byte value * 8
+    return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(lut) + off);
+}
+
 __global__ __launch_bounds__(64 * kWavesPerBlock)
 void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, const uint2* __restrict__ rows16,
                      const uint32_t nrows_padded, const int64_t first_diag, const uint32_t tile_begin,
@@ -227,6 +235,11 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
                      const uint64_t hit_capacity, const uint32_t* __restrict__ abort_flag) {
     __shared__ uint64_t hit_stage[kWavesPerBlock][kHitStage];
     __shared__ uint32_t hit_masks[kWavesPerBlock][kChunkRows * 64];
+    __shared__ uint2 selector_lut[256];
+
+    // table entry b: selectors of symbol pairs (s0,s1) and (s2,s3) of packed byte b
+    selector_lut[threadIdx.x] = make_uint2(pair_selector(threadIdx.x, 0), pair_selector(threadIdx.x, 4));
+    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     // readfirstlane: everything derived from the tile index is wave-uniform, which lets hipcc keep
@@ -250,49 +263,58 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
 #pragma unroll
     for (int i = 0; i < kRegs; i++) x[i] = kScoreZero;
 
-    // symbol window of the current chunk: positions [j, j+64), j = dl + p0
-    bool edge = (d0 + p_lo < 0) || (d0 + p_lo + kTileDiags + kChunkRows > nsymbols);
-    uint2 hi = load_symbols(seq, nsymbols, dl + p_lo, edge);
+    // Selector window of the current chunk, symbol positions [j, j+64) with j = dl + p0:
+    // W[k] serves symbols (j+2k, j+2k+1), Wodd[k] symbols (j+2k+1, j+2k+2).  The upper half of one
+    // chunk's window is the lower half of the next, so each chunk expands only 32 new symbols.
+    uint32_t W[32], Wodd[31];
+    auto expand = [&](int64_t rel, int base) {     // symbols [dl+rel, dl+rel+32) -> W[base .. base+16); rel is wave-uniform
+        const bool edge = (d0 + rel < 0) || (d0 + rel + kTileDiags > nsymbols);   // the wave's 2048 positions
+        const int64_t pos = dl + rel;
+        const uint2 packed = load_symbols(seq, nsymbols, pos, edge);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint2 s0 = byte_selectors(selector_lut, packed.x, b);
+            const uint2 s1 = byte_selectors(selector_lut, packed.y, b);
+            W[base + 2 * b] = s0.x;     W[base + 2 * b + 1] = s0.y;
+            W[base + 8 + 2 * b] = s1.x; W[base + 8 + 2 * b + 1] = s1.y;
+        }
+        if (edge) {
+            // positions outside [0, N) score -256: pins the cell at 0, never hits
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int64_t q = pos + 2 * k;     // q and q+1 are in or out together (pos, N even)
+                if (q < 0 || q >= nsymbols) W[base + k] = kPadSelector;
+            }
+        }
+    };
+    expand(p_lo, 16);
 
     for (int64_t p0 = p_lo; p0 < p_hi; p0 += kChunkRows) {
         if (abort_flag && ((p0 & 2047) == 0) &&
             __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
-        // all rows of the chunk are fetched up front (one batch of scalar loads, one wait)
+        // rows of the chunk: fetched in two batches of scalar loads, the second lands while rows 0..15 run
         const const_rows_t rows = (const_rows_t)(const row16_t*)(rows16 + p0);
         row16_t row[kChunkRows];
 #pragma unroll
         for (int r = 0; r < kChunkRows / 2; r++) row[r] = rows[r];
 
-        const int64_t j = dl + p0;
-        edge = (d0 + p0 < 0) || (d0 + p0 + kTileDiags + kChunkRows > nsymbols);
-        const uint2 lo = hi;
-        hi = load_symbols(seq, nsymbols, j + 32, edge);
-
-        // selectors: W[k] for symbols (2k, 2k+1), Wodd[k] for (2k+1, 2k+2)
-        uint32_t W[32], Wodd[31];
+        // slide the window by 32 symbols
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            W[k] = pair_selector(lo.x, k * 4);
-            W[k + 8] = pair_selector(lo.y, k * 4);
-            W[k + 16] = pair_selector(hi.x, k * 4);
-            W[k + 24] = pair_selector(hi.y, k * 4);
-        }
-        if (edge) {
-            // positions outside [0, N) score -256: pins the cell at 0, never hits
+        for (int k = 0; k < 16; k++) W[k] = W[k + 16];
 #pragma unroll
-            for (int k = 0; k < 32; k++) {
-                const int64_t pos = j + 2 * k;     // pos and pos+1 are in or out together (j, N even)
-                if (pos < 0 || pos >= nsymbols) W[k] = kPadSelector;
-            }
+        for (int k = 0; k < 15; k++) Wodd[k] = Wodd[k + 16];
+        expand(p0 + 32, 16);
+        if (p0 == p_lo) {
+#pragma unroll
+            for (int k = 0; k < 15; k++) Wodd[k] = __builtin_amdgcn_alignbit(W[k + 1], W[k], 16);
         }
 #pragma unroll
-        for (int k = 0; k < 31; k++) {
-            Wodd[k] = __builtin_amdgcn_alignbit(W[k + 1], W[k], 16);
-            asm volatile("" : "+v"(Wodd[k]));   // keep it in a VGPR: hipcc otherwise recomputes it in every odd row
-        }
-
+        for (int k = 15; k < 31; k++) Wodd[k] = __builtin_amdgcn_alignbit(W[k + 1], W[k], 16);
 #pragma unroll
-        for (int r = kChunkRows / 2; r < kChunkRows; r++) row[r] = rows[r];   // lands while rows 0..15 run
+        for (int k = 0; k < 31; k++) asm volatile("" : "+v"(Wodd[k]));   // keep in VGPRs: hipcc otherwise
+                                                                          // recomputes them in every odd row
+#pragma unroll
+        for (int r = kChunkRows / 2; r < kChunkRows; r++) row[r] = rows[r];
 
         uint32_t rows_with_hits = 0;   // wave-uniform
         chunk_rows(x, W, Wodd, row, sink.row_masks, rows_with_hits, lane, std::make_integer_sequence<int, kChunkRows>{});
