@@ -1,0 +1,166 @@
+// Havac.cpp -- host/Havac.cpp:20-206 on top of the C ABI of libhavac_dev.so.
+#include "Havac.hpp"
+
+#include <cstdlib>
+#include <iostream>
+#include <new>
+#include <sstream>
+#include <stdexcept>
+
+#include "../../../include/havac_dev.h"
+#include "PhmmPreprocessor.hpp"
+#include "SequencePreprocessor.hpp"
+
+// ---- error mapping (include/havac_dev.h names the reference's exception per code) ----
+void Havac::check(int code) {
+    if (code >= 0) return;
+    const char *msg = dev_ ? havac_dev_last_error(dev_) : "";
+    switch (code) {
+        case HAVAC_E_LENGTH: throw std::length_error(msg);
+        case HAVAC_E_LOGIC: throw std::logic_error(msg);
+        case HAVAC_E_NOMEM: throw std::bad_alloc();
+        case HAVAC_E_HIT_OVERFLOW: throw std::overflow_error(msg);
+        default: throw std::runtime_error(msg && *msg ? msg : "havac device error");
+    }
+}
+
+Havac::Havac(const uint32_t deviceIndex, const float requiredPValue, const std::string)
+    : deviceIndex(deviceIndex), requiredPValue(requiredPValue) {
+    int rc = havac_dev_create(deviceIndex, &dev_);
+    if (rc == HAVAC_E_NOMEM) throw std::bad_alloc();
+    if (rc != HAVAC_OK) throw std::runtime_error("ERROR: could not open MI355X device " + std::to_string(deviceIndex));
+    fastaVector = static_cast<FastaVector *>(std::malloc(sizeof(FastaVector)));
+    p7HmmList = static_cast<P7HmmList *>(std::calloc(1, sizeof(P7HmmList)));
+    if (!fastaVector || !p7HmmList || fastaVectorInit(fastaVector) == FASTA_VECTOR_ALLOCATION_FAIL) {
+        std::free(fastaVector); std::free(p7HmmList);
+        havac_dev_destroy(dev_);
+        throw std::bad_alloc();
+    }
+}
+
+Havac::~Havac() {
+    fastaVectorDealloc(fastaVector);
+    p7HmmListDealloc(p7HmmList);
+    std::free(fastaVector);
+    std::free(p7HmmList);
+    havac_dev_destroy(dev_);
+}
+
+void Havac::loadPhmm(const std::string phmmSrc) {
+    p7HmmListDealloc(p7HmmList);
+    enum P7HmmReturnCode rc = readP7Hmm(phmmSrc.c_str(), p7HmmList);
+    // host/Havac.cpp:44-50.  The reference's test for p7HmmFileNotFound is a dangling `if` that
+    // falls through to preprocessing an uninitialised list; here a missing file is an error.
+    if (rc == p7HmmFileNotFound) throw std::runtime_error("Could not open phmm file for reading.");
+    if (rc == p7HmmAllocationFailure) throw std::bad_alloc();
+    if (rc == p7HmmFormatError) throw std::runtime_error("Phmm file was not formatted correctly.");
+    PhmmPreprocessor preprocessor(p7HmmList, requiredPValue);
+    compressedPhmmScores = preprocessor.getProcessedPhmmData();
+    check(havac_dev_write_phmm(dev_, compressedPhmmScores->data(), compressedPhmmScores->size()));
+    phmmLoadedToDevice = true;
+}
+
+void Havac::loadSequence(const std::string fastaSrc) {
+    enum FastaVectorReturnCode rc = fastaVectorReadFasta(fastaSrc.c_str(), fastaVector);   // appends, as the reference does
+    if (rc == FASTA_VECTOR_ALLOCATION_FAIL) throw std::bad_alloc();
+    if (rc == FASTA_VECTOR_FILE_OPEN_FAIL) throw std::runtime_error("Could not open fasta file for reading.");
+    if (rc == FASTA_VECTOR_FILE_READ_FAIL) throw std::runtime_error("Error while reading from the opened fasta file.");
+    SequencePreprocessor preprocessor(fastaVector);
+    vector<uint8_t> &packed = preprocessor.getCompressedSequenceBuffer();
+    check(havac_dev_write_sequence(dev_, packed.data(), packed.size()));
+    sequenceLoadedToDevice = true;
+}
+
+void Havac::runHardwareClient() {
+    runHardwareClientAsync();
+    waitHardwareClientAsync();
+}
+
+void Havac::runHardwareClientAsync() {
+    if (!phmmLoadedToDevice)   // host/Havac.cpp:86-88
+        throw std::logic_error("Phmm was not loaded to device before hardware was requested to run.");
+    if (!sequenceLoadedToDevice)   // :89-91
+        throw std::logic_error("Sequence was not loaded to device before hardware was requested to run.");
+    check(havac_dev_run_async(dev_));
+}
+
+void Havac::waitHardwareClientAsync() { check(havac_dev_wait(dev_, 0)); }
+
+void Havac::abortHardwareClient() { check(havac_dev_abort(dev_)); }
+
+enum havac_cmd_state Havac::currentHardwareState() {
+    int s = havac_dev_state(dev_);
+    check(s);
+    return (havac_cmd_state)s;
+}
+
+void Havac::setHitCapacity(uint64_t maxHits) { check(havac_dev_set_hit_capacity(dev_, maxHits)); }
+
+void Havac::lastRunMilliseconds(float *ssvKernelMs, float *totalMs) {
+    check(havac_dev_last_run_ms(dev_, ssvKernelMs, totalMs));
+}
+
+vector<uint32_t> Havac::generatePhmmLenPrefixSums() {   // host/Havac.cpp:104-116
+    vector<uint32_t> sums(1, 0u);
+    sums.reserve(p7HmmList->count + 1);
+    for (uint32_t i = 0; i < p7HmmList->count; i++) sums.push_back(sums.back() + p7HmmList->phmms[i].header.modelLength);
+    return sums;
+}
+
+// largest index whose prefix sum is <= the global row (host/Havac.cpp:119-142)
+PhmmLocalPosition phmmPrefixSumsBinarySearch(uint32_t phmmGlobalPosition, vector<uint32_t> &prefixSums) {
+    int32_t lo = 0, hi = (int32_t)prefixSums.size() - 1, found = -1;
+    while (lo <= hi) {
+        int32_t mid = lo + (hi - lo) / 2;
+        if (prefixSums[mid] <= phmmGlobalPosition) { found = mid; lo = mid + 1; } else { hi = mid - 1; }
+    }
+    PhmmLocalPosition p;
+    p.phmmIndex = found;
+    p.phmmPosition = found >= 0 ? phmmGlobalPosition - prefixSums[found] : 0;
+    return p;
+}
+
+vector<HavacHit> havacResolveHits(const vector<uint64_t> &rawHits, const FastaVector *fastaVector,
+                                  vector<uint32_t> &phmmPrefixSums) {
+    vector<HavacHit> out;
+    out.reserve(rawHits.size());
+    for (size_t i = 0; i < rawHits.size(); i++) {
+        const uint64_t rec = rawHits[i];
+        // [13:0] column in segment, [39:14] segment, [63:40] row (host/Havac.cpp:155-163)
+        const uint64_t inSegment = rec & ((1ull << 14) - 1);
+        const uint64_t segment = (rec & ((1ull << 40) - 1)) >> 14;
+        const uint64_t globalSequencePosition = segment * (12 * 1024) + inSegment;
+        const uint32_t globalPhmmPosition = (uint32_t)(rec >> 40);
+        FastaVectorLocalPosition local;
+        if (!fastaVectorGetLocalSequencePositionFromGlobal(fastaVector, globalSequencePosition, &local))
+            continue;   // a hit in the padding after the last record (host/Havac.cpp:169-173)
+        PhmmLocalPosition where = phmmPrefixSumsBinarySearch(globalPhmmPosition, phmmPrefixSums);
+        if (where.phmmIndex == -1) {
+            std::cerr << "ERROR: could not resolve phmm position for raw hit report #" << i << "\n" << std::endl;
+            continue;
+        }
+        out.push_back(HavacHit(local.positionInSequence, (uint32_t)local.sequenceIndex, where.phmmPosition,
+                               (uint32_t)where.phmmIndex));
+    }
+    return out;
+}
+
+vector<HavacHit> Havac::getHitsFromFinishedRun() {
+    uint32_t n = 0;
+    check(havac_dev_num_hits(dev_, &n));
+    rawHits_.assign(n, 0);
+    if (n) check(havac_dev_read_hits(dev_, rawHits_.data(), n));
+    vector<uint32_t> sums = generatePhmmLenPrefixSums();
+    return havacResolveHits(rawHits_, fastaVector, sums);
+}
+
+HavacHit::HavacHit(const uint64_t sequencePosition, const uint32_t sequenceIndex, const uint32_t phmmPosition,
+                   const uint32_t phmmIndex)
+    : sequencePosition(sequencePosition), sequenceIndex(sequenceIndex), phmmPosition(phmmPosition), phmmIndex(phmmIndex) {}
+
+std::string HavacHit::toString() {   // host/Havac.cpp:201-206, same text
+    std::stringstream ss;
+    ss << "sequence $" << sequenceIndex << ", position " << sequencePosition << "; phmm #" << phmmIndex << " position "
+       << phmmPosition;
+    return ss.str();
+}

@@ -1,0 +1,94 @@
+// Havac.hpp -- the reference's public C++ API (host/Havac.hpp:16-107) on an MI355X.
+//
+// Drop-in: same enum, same classes, same method names, argument meaning and exception
+// types.  What changed underneath: the XRT/HavacHwClient device path is gone; this
+// class talks to libhavac_dev.so through the C ABI in include/havac_dev.h, and the
+// un-vendored FastaVector / P7HmmReader libraries are replaced by the small readers
+// in this directory.  No XRT, boost or Vitis header is needed to include this file.
+#ifndef HAVAC_HOST_HPP
+#define HAVAC_HOST_HPP
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "FastaVector.h"
+#include "p7HmmReader.h"
+
+using std::shared_ptr;
+using std::vector;
+
+// host/Havac.hpp:16-26 (numerically XRT's ert_cmd_state)
+enum havac_cmd_state {
+    HAVAC_CMD_STATE_NEW = 1,
+    HAVAC_CMD_STATE_QUEUED = 2,
+    HAVAC_CMD_STATE_RUNNING = 3,
+    HAVAC_CMD_STATE_COMPLETED = 4,
+    HAVAC_CMD_STATE_ERROR = 5,
+    HAVAC_CMD_STATE_ABORT = 6,
+    HAVAC_CMD_STATE_SUBMITTED = 7,
+    HAVAC_CMD_STATEIMEOUT = 8,      // (sic) the reference's spelling
+    HAVAC_CMD_STATE_NORESPONSE = 9
+};
+
+// kept for source compatibility; there is no bitstream, the argument is ignored
+const std::string xclbinSrcDefault = "../device/bin/havac.xclbin";
+
+class HavacHit {   // host/Havac.hpp:31-39
+public:
+    HavacHit(const uint64_t sequencePosition, const uint32_t sequenceIndex, const uint32_t phmmPosition,
+             const uint32_t phmmIndex);
+    uint64_t sequencePosition;
+    uint32_t sequenceIndex;
+    uint32_t phmmPosition;
+    uint32_t phmmIndex;
+    std::string toString();
+};
+
+struct havac_dev;   // include/havac_dev.h
+
+class Havac {       // host/Havac.hpp:42-107
+public:
+    Havac(const uint32_t deviceIndex = 0, const float requiredPValue = 0.02f,
+          const std::string xclbinSrc = xclbinSrcDefault);
+    Havac(Havac &&havac) = delete;
+    Havac(Havac &havac) = delete;
+    ~Havac();
+
+    void loadSequence(const std::string fastaSrc);
+    void loadPhmm(const std::string phmmSrc);
+    void runHardwareClient();
+    void runHardwareClientAsync();
+    void waitHardwareClientAsync();
+    void abortHardwareClient();
+    vector<HavacHit> getHitsFromFinishedRun();
+    enum havac_cmd_state currentHardwareState();
+
+    // ---- additions (not in the reference) ----
+    void setHitCapacity(uint64_t maxHits);                 // the reference's buffer is a fixed 3.5 GiB
+    void lastRunMilliseconds(float *ssvKernelMs, float *totalMs);
+    const vector<uint64_t> &rawHitsOfLastFetch() const { return rawHits_; }
+
+private:
+    void check(int code);                                  // C-ABI code -> the reference's exception types
+    vector<uint32_t> generatePhmmLenPrefixSums();
+
+    havac_dev *dev_ = nullptr;
+    FastaVector *fastaVector = nullptr;
+    P7HmmList *p7HmmList = nullptr;
+    shared_ptr<vector<int8_t>> compressedPhmmScores;
+    uint32_t deviceIndex;
+    float requiredPValue;
+    bool phmmLoadedToDevice = false;
+    bool sequenceLoadedToDevice = false;
+    vector<uint64_t> rawHits_;
+};
+
+// The resolver of host/Havac.cpp:145-187 as a free function (testable without a device):
+// raw 64-bit records -> HavacHit, dropping hits in the padding after the last record.
+struct PhmmLocalPosition { int32_t phmmIndex; uint32_t phmmPosition; };
+PhmmLocalPosition phmmPrefixSumsBinarySearch(uint32_t phmmGlobalPosition, vector<uint32_t> &prefixSums);
+vector<HavacHit> havacResolveHits(const vector<uint64_t> &rawHits, const FastaVector *fastaVector,
+                                  vector<uint32_t> &phmmPrefixSums);
+#endif

@@ -1,0 +1,55 @@
+// SequencePreprocessor.cpp -- restates host/sequence/SequencePreprocessor.cpp:9-84.
+//
+// Quirks kept on purpose, because they decide which symbol lands in which column:
+//  * the length is sequence.count INCLUDING the '\0' after every record (:12-13); each '\0', 'N'
+//    or other unknown character becomes a random nucleotide;
+//  * for any non-ACGT character rand()%2 is drawn first (:74); two-fold ambiguity codes use that
+//    draw, everything else draws rand()%4 afterwards (:82) -- the rand() call ORDER is kept, so a
+//    caller that seeds with srand(s) gets the reference's sequence for the same libc;
+//  * 'Y' returns randMod2 << 1 + 1, which C parses as randMod2 << 2, i.e. 0 or 4 (:77).  The value 4
+//    sets a bit of the NEXT symbol's field, which that symbol's own masked write then clears unless
+//    'Y' is the very last character;
+//  * padding bytes are zero, i.e. symbol 0 = 'A' (:41).
+#include "SequencePreprocessor.hpp"
+
+#include <cstdlib>
+
+namespace {
+constexpr uint32_t kSegment = 12288;   // NUM_CELL_PROCESSORS, device/PublicDefines.h:18-22
+}
+
+SequencePreprocessor::SequencePreprocessor(FastaVector *fastaVector) {
+    originalLength_ = (uint32_t)fastaVector->sequence.count;
+    segments_ = (originalLength_ + (kSegment - 1)) / kSegment;
+    symbols_ = segments_ * kSegment;
+    bytes_ = symbols_ / 4;
+    packed_.assign(bytes_, 0);
+    const char *chars = fastaVector->sequence.charData;
+    for (uint32_t i = 0; i < fastaVector->sequence.count; i++) {
+        const uint8_t code = getCompressedSymbol(chars[i]);
+        const uint32_t byte = i / 4;
+        const uint8_t shift = (uint8_t)((i % 4) * 2);
+        packed_[byte] &= (uint8_t)~(uint8_t)(0x3u << shift);     // clear this symbol's field (:52-54)
+        packed_[byte] |= (uint8_t)(code << shift);               // the unmasked OR of :56-57
+    }
+}
+
+uint8_t SequencePreprocessor::getCompressedSymbol(const char c) {
+    switch (c) {
+        case 'a': case 'A': return 0;
+        case 'c': case 'C': return 1;
+        case 'g': case 'G': return 2;
+        case 't': case 'T': return 3;
+        default: break;
+    }
+    const uint8_t coin = (uint8_t)(std::rand() % 2);             // drawn for EVERY other character (:74)
+    switch (c) {
+        case 'r': case 'R': return (uint8_t)(coin * 2);          // A or G
+        case 'y': case 'Y': return (uint8_t)(coin << 2);         // reference: coin << 1 + 1  ==  coin << 2
+        case 's': case 'S': return (uint8_t)(coin + 1);          // C or G
+        case 'w': case 'W': return (uint8_t)(coin * 3);          // A or T
+        case 'k': case 'K': return (uint8_t)(coin + 2);          // G or T
+        case 'm': case 'M': return coin;                         // A or C
+        default: return (uint8_t)(std::rand() % 4);              // '\0', N, 3-fold codes, anything else (:82)
+    }
+}

@@ -1,0 +1,167 @@
+// havac_host_c.cpp -- include/havac_host.h: C wrappers around class Havac and the host-only stages.
+#include "../../../include/havac_host.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
+
+#include "../../../include/havac_dev.h"
+#include "Havac.hpp"
+#include "PhmmPreprocessor.hpp"
+#include "PhmmReprojection.h"
+#include "SequencePreprocessor.hpp"
+
+struct havac_host {
+    Havac *obj = nullptr;
+    std::string err;
+    vector<HavacHit> hits;
+    bool haveHits = false;
+};
+
+namespace {
+template <typename F>
+int guarded(havac_host *h, F &&f) {
+    try {
+        f();
+        return HAVAC_OK;
+    } catch (const std::length_error &e) { if (h) h->err = e.what(); return HAVAC_E_LENGTH;
+    } catch (const std::overflow_error &e) { if (h) h->err = e.what(); return HAVAC_E_HIT_OVERFLOW;
+    } catch (const std::logic_error &e) { if (h) h->err = e.what(); return HAVAC_E_LOGIC;
+    } catch (const std::bad_alloc &e) { if (h) h->err = e.what(); return HAVAC_E_NOMEM;
+    } catch (const std::exception &e) { if (h) h->err = e.what(); return HAVAC_E_RUNTIME; }
+}
+
+int copyHits(const vector<HavacHit> &hits, uint64_t *sp, uint32_t *si, uint32_t *pp, uint32_t *pi, uint32_t cap,
+             uint32_t *count) {
+    if (count) *count = (uint32_t)hits.size();
+    for (uint32_t i = 0; i < cap && i < hits.size(); i++) {
+        if (sp) sp[i] = hits[i].sequencePosition;
+        if (si) si[i] = hits[i].sequenceIndex;
+        if (pp) pp[i] = hits[i].phmmPosition;
+        if (pi) pi[i] = hits[i].phmmIndex;
+    }
+    return HAVAC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int havac_host_create(uint32_t device_index, float p, havac_host **out) {
+    if (!out) return HAVAC_E_ARGUMENT;
+    *out = nullptr;
+    havac_host *h = new (std::nothrow) havac_host;
+    if (!h) return HAVAC_E_NOMEM;
+    int rc = guarded(h, [&] { h->obj = new Havac(device_index, p); });
+    if (rc != HAVAC_OK) { delete h; return rc == HAVAC_E_RUNTIME ? HAVAC_E_NO_DEVICE : rc; }
+    *out = h;
+    return HAVAC_OK;
+}
+
+void havac_host_destroy(havac_host *h) {
+    if (!h) return;
+    delete h->obj;
+    delete h;
+}
+
+const char *havac_host_last_error(havac_host *h) { return h ? h->err.c_str() : "null handle"; }
+
+int havac_host_load_sequence(havac_host *h, const char *p) { return guarded(h, [&] { h->obj->loadSequence(p); }); }
+int havac_host_load_phmm(havac_host *h, const char *p) { return guarded(h, [&] { h->obj->loadPhmm(p); }); }
+int havac_host_run(havac_host *h) { h->haveHits = false; return guarded(h, [&] { h->obj->runHardwareClient(); }); }
+int havac_host_run_async(havac_host *h) { h->haveHits = false; return guarded(h, [&] { h->obj->runHardwareClientAsync(); }); }
+int havac_host_wait(havac_host *h) { return guarded(h, [&] { h->obj->waitHardwareClientAsync(); }); }
+int havac_host_abort(havac_host *h) { return guarded(h, [&] { h->obj->abortHardwareClient(); }); }
+int havac_host_set_hit_capacity(havac_host *h, uint64_t n) { return guarded(h, [&] { h->obj->setHitCapacity(n); }); }
+
+int havac_host_state(havac_host *h) {
+    int s = 0;
+    int rc = guarded(h, [&] { s = (int)h->obj->currentHardwareState(); });
+    return rc == HAVAC_OK ? s : rc;
+}
+
+int havac_host_get_hits(havac_host *h, uint64_t *sp, uint32_t *si, uint32_t *pp, uint32_t *pi, uint32_t cap,
+                        uint32_t *count) {
+    if (!h->haveHits) {
+        int rc = guarded(h, [&] { h->hits = h->obj->getHitsFromFinishedRun(); });
+        if (rc != HAVAC_OK) return rc;
+        h->haveHits = true;
+    }
+    return copyHits(h->hits, sp, si, pp, pi, cap, count);
+}
+
+int havac_host_get_raw_hits(havac_host *h, uint64_t *out, uint32_t cap, uint32_t *count) {
+    const vector<uint64_t> &raw = h->obj->rawHitsOfLastFetch();
+    if (count) *count = (uint32_t)raw.size();
+    for (uint32_t i = 0; i < cap && i < raw.size(); i++) out[i] = raw[i];
+    return HAVAC_OK;
+}
+
+int havac_host_last_run_ms(havac_host *h, float *a, float *b) {
+    return guarded(h, [&] { h->obj->lastRunMilliseconds(a, b); });
+}
+
+// ---- host-only stages ------------------------------------------------------
+
+int havac_host_pack_fasta(const char *path, int64_t seed, uint8_t *out, uint64_t cap, uint64_t *nbytes,
+                          uint64_t *nchars, uint32_t *nrecords) {
+    FastaVector fv;
+    if (fastaVectorInit(&fv) != FASTA_VECTOR_OK) return HAVAC_E_NOMEM;
+    FastaVectorReturnCode rc = fastaVectorReadFasta(path, &fv);
+    if (rc != FASTA_VECTOR_OK) { fastaVectorDealloc(&fv); return rc == FASTA_VECTOR_ALLOCATION_FAIL ? HAVAC_E_NOMEM : HAVAC_E_RUNTIME; }
+    if (seed >= 0) std::srand((unsigned)seed);
+    SequencePreprocessor pre(&fv);
+    vector<uint8_t> &packed = pre.getCompressedSequenceBuffer();
+    if (nbytes) *nbytes = packed.size();
+    if (nchars) *nchars = fv.sequence.count;
+    if (nrecords) *nrecords = (uint32_t)fv.metadata.count;
+    if (out && cap >= packed.size()) std::memcpy(out, packed.data(), packed.size());
+    fastaVectorDealloc(&fv);
+    return HAVAC_OK;
+}
+
+int havac_host_project_hmm(const char *path, float p, int8_t *out, uint64_t cap, uint64_t *nbytes, uint32_t *nmodels,
+                           uint32_t *lengths, uint32_t lengths_cap) {
+    P7HmmList list;
+    P7HmmReturnCode rc = readP7Hmm(path, &list);
+    if (rc == p7HmmAllocationFailure) return HAVAC_E_NOMEM;
+    if (rc != p7HmmSuccess) return HAVAC_E_RUNTIME;
+    PhmmPreprocessor pre(&list, p);
+    auto data = pre.getProcessedPhmmData();
+    if (nbytes) *nbytes = data->size();
+    if (nmodels) *nmodels = list.count;
+    for (uint32_t i = 0; lengths && i < list.count && i < lengths_cap; i++) lengths[i] = list.phmms[i].header.modelLength;
+    if (out && cap >= data->size()) std::memcpy(out, data->data(), data->size());
+    p7HmmListDealloc(&list);
+    return HAVAC_OK;
+}
+
+float havac_host_scaling_factor(float mu, float lambda, uint32_t max_length, uint32_t model_length, float p) {
+    P7Hmm h;
+    std::memset(&h, 0, sizeof h);
+    h.stats.msvGumbelMu = mu; h.stats.msvGumbelLambda = lambda;
+    h.header.maxLength = max_length; h.header.modelLength = model_length;
+    return findThreshold256ScalingFactor(&h, p);
+}
+
+float havac_host_project_score(float s, float m) { return emissionScoreToProjectedScore(s, m); }
+
+int havac_host_resolve_hits(const char *fasta, const char *hmm, const uint64_t *raw, uint32_t nraw, uint64_t *sp,
+                            uint32_t *si, uint32_t *pp, uint32_t *pi, uint32_t cap, uint32_t *count) {
+    FastaVector fv;
+    if (fastaVectorInit(&fv) != FASTA_VECTOR_OK) return HAVAC_E_NOMEM;
+    if (fastaVectorReadFasta(fasta, &fv) != FASTA_VECTOR_OK) { fastaVectorDealloc(&fv); return HAVAC_E_RUNTIME; }
+    P7HmmList list;
+    if (readP7Hmm(hmm, &list) != p7HmmSuccess) { fastaVectorDealloc(&fv); return HAVAC_E_RUNTIME; }
+    vector<uint32_t> sums(1, 0u);
+    for (uint32_t i = 0; i < list.count; i++) sums.push_back(sums.back() + list.phmms[i].header.modelLength);
+    vector<uint64_t> r(raw, raw + nraw);
+    vector<HavacHit> hits = havacResolveHits(r, &fv, sums);
+    copyHits(hits, sp, si, pp, pi, cap, count);
+    p7HmmListDealloc(&list);
+    fastaVectorDealloc(&fv);
+    return HAVAC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+"""ctypes view of the C++ `Havac` class (libhavac.so, include/havac_host.h).
+
+`Havac` here has the reference's method names (host/Havac.hpp:42-107); every
+call goes straight into the C++ object, which drives the GPU through
+libhavac_dev.so.  The host-only helpers at the bottom run the reference's CPU
+stages (FASTA packing, model projection, hit resolution) and need no device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .hw_client import raise_for
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "libhavac.so")
+
+_vp = C.c_void_p
+HOST_SIGNATURES = {
+    "havac_host_create": (C.c_int, [C.c_uint32, C.c_float, C.POINTER(C.c_void_p)]),
+    "havac_host_destroy": (None, [_vp]),
+    "havac_host_load_sequence": (C.c_int, [_vp, C.c_char_p]),
+    "havac_host_load_phmm": (C.c_int, [_vp, C.c_char_p]),
+    "havac_host_run": (C.c_int, [_vp]),
+    "havac_host_run_async": (C.c_int, [_vp]),
+    "havac_host_wait": (C.c_int, [_vp]),
+    "havac_host_abort": (C.c_int, [_vp]),
+    "havac_host_state": (C.c_int, [_vp]),
+    "havac_host_set_hit_capacity": (C.c_int, [_vp, C.c_uint64]),
+    "havac_host_get_hits": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "havac_host_get_raw_hits": (C.c_int, [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "havac_host_last_run_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "havac_host_last_error": (C.c_char_p, [_vp]),
+    "havac_host_pack_fasta": (C.c_int, [C.c_char_p, C.c_int64, _vp, C.c_uint64, C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "havac_host_project_hmm": (C.c_int, [C.c_char_p, C.c_float, _vp, C.c_uint64, C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint32), _vp, C.c_uint32]),
+    "havac_host_scaling_factor": (C.c_float, [C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_float]),
+    "havac_host_project_score": (C.c_float, [C.c_float, C.c_float]),
+    "havac_host_resolve_hits": (C.c_int, [C.c_char_p, C.c_char_p, _vp, C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint32,
+                                          C.POINTER(C.c_uint32)]),
+}
+
+_host = None
+
+
+def load_host() -> C.CDLL:
+    global _host
+    if _host is None:
+        _lib.load()       # libhavac.so links libhavac_dev.so; fail on that one first, with its message
+        if not os.path.isfile(HOST_LIB_PATH):
+            raise ImportError(f"{HOST_LIB_PATH} is missing: build it with havac_amd/csrc/host/build.sh")
+        lib = C.CDLL(HOST_LIB_PATH)
+        for name, (res, args) in HOST_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _host = lib
+    return _host
+
+
+@dataclass(frozen=True)
+class HavacHit:      # host/Havac.hpp:31-39
+    sequencePosition: int
+    sequenceIndex: int
+    phmmPosition: int
+    phmmIndex: int
+
+    def toString(self) -> str:
+        return (f"sequence ${self.sequenceIndex}, position {self.sequencePosition}; "
+                f"phmm #{self.phmmIndex} position {self.phmmPosition}")
+
+
+def _hits_from_arrays(sp, si, pp, pi):
+    return [HavacHit(int(a), int(b), int(c), int(d)) for a, b, c, d in zip(sp, si, pp, pi)]
+
+
+class Havac:
+    def __init__(self, deviceIndex: int = 0, requiredPValue: float = 0.02, xclbinSrc: str = ""):
+        self._L = load_host()
+        h = C.c_void_p()
+        rc = self._L.havac_host_create(deviceIndex, requiredPValue, C.byref(h))
+        if rc != 0:
+            raise_for(rc, "could not create Havac (no gfx950 device?)")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.havac_host_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise_for(rc, (self._L.havac_host_last_error(self._h) or b"").decode())
+        return rc
+
+    def loadSequence(self, fastaSrc: str):
+        self._check(self._L.havac_host_load_sequence(self._h, os.fsencode(fastaSrc)))
+
+    def loadPhmm(self, phmmSrc: str):
+        self._check(self._L.havac_host_load_phmm(self._h, os.fsencode(phmmSrc)))
+
+    def runHardwareClient(self):
+        self._check(self._L.havac_host_run(self._h))
+
+    def runHardwareClientAsync(self):
+        self._check(self._L.havac_host_run_async(self._h))
+
+    def waitHardwareClientAsync(self):
+        self._check(self._L.havac_host_wait(self._h))
+
+    def abortHardwareClient(self):
+        self._check(self._L.havac_host_abort(self._h))
+
+    def currentHardwareState(self) -> int:
+        return self._check(self._L.havac_host_state(self._h))
+
+    def setHitCapacity(self, n: int):
+        self._check(self._L.havac_host_set_hit_capacity(self._h, n))
+
+    def getHitsFromFinishedRun(self):
+        n = C.c_uint32(0)
+        self._check(self._L.havac_host_get_hits(self._h, None, None, None, None, 0, C.byref(n)))
+        sp = np.empty(n.value, np.uint64)
+        si, pp, pi = (np.empty(n.value, np.uint32) for _ in range(3))
+        self._check(self._L.havac_host_get_hits(self._h, sp.ctypes.data, si.ctypes.data, pp.ctypes.data,
+                                                pi.ctypes.data, n.value, C.byref(n)))
+        return _hits_from_arrays(sp, si, pp, pi)
+
+    def rawHits(self) -> np.ndarray:
+        n = C.c_uint32(0)
+        self._check(self._L.havac_host_get_raw_hits(self._h, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.uint64)
+        self._check(self._L.havac_host_get_raw_hits(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def lastRunMs(self):
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(self._L.havac_host_last_run_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+# ---- host-only stages (no device) --------------------------------------------
+
+def pack_fasta(path: str, seed: int = -1):
+    """FastaVector + SequencePreprocessor -> (packed uint8, nchars incl. terminators, nrecords)."""
+    L = load_host()
+    nb, nc, nr = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+    rc = L.havac_host_pack_fasta(os.fsencode(path), -1, None, 0, C.byref(nb), C.byref(nc), C.byref(nr))
+    if rc != 0:
+        raise_for(rc, f"could not read {path}")
+    out = np.empty(nb.value, np.uint8)
+    rc = L.havac_host_pack_fasta(os.fsencode(path), seed, out.ctypes.data, out.size, C.byref(nb), C.byref(nc), C.byref(nr))
+    if rc != 0:
+        raise_for(rc, f"could not read {path}")
+    return out, nc.value, nr.value
+
+
+def project_hmm(path: str, p_value: float = 0.02):
+    """P7HmmReader + PhmmPreprocessor -> (int8 [rows,4], model lengths)."""
+    L = load_host()
+    nb, nm = C.c_uint64(0), C.c_uint32(0)
+    rc = L.havac_host_project_hmm(os.fsencode(path), p_value, None, 0, C.byref(nb), C.byref(nm), None, 0)
+    if rc != 0:
+        raise_for(rc, f"could not read {path}")
+    out = np.empty(nb.value, np.int8)
+    lens = np.empty(nm.value, np.uint32)
+    rc = L.havac_host_project_hmm(os.fsencode(path), p_value, out.ctypes.data, out.size, C.byref(nb), C.byref(nm),
+                                  lens.ctypes.data, lens.size)
+    if rc != 0:
+        raise_for(rc, f"could not read {path}")
+    return out.reshape(-1, 4), lens
+
+
+def scaling_factor(mu, lam, max_length, model_length, p_value) -> float:
+    return float(load_host().havac_host_scaling_factor(mu, lam, max_length, model_length, p_value))
+
+
+def project_score(emission_score, multiplier) -> float:
+    return float(load_host().havac_host_project_score(emission_score, multiplier))
+
+
+def resolve_hits(fasta_path: str, hmm_path: str, raw: np.ndarray):
+    L = load_host()
+    raw = np.ascontiguousarray(raw, np.uint64)
+    n = C.c_uint32(0)
+    sp = np.empty(raw.size, np.uint64)
+    si, pp, pi = (np.empty(raw.size, np.uint32) for _ in range(3))
+    rc = L.havac_host_resolve_hits(os.fsencode(fasta_path), os.fsencode(hmm_path), raw.ctypes.data, raw.size,
+                                   sp.ctypes.data, si.ctypes.data, pp.ctypes.data, pi.ctypes.data, raw.size, C.byref(n))
+    if rc != 0:
+        raise_for(rc, "could not resolve hits")
+    k = n.value
+    return _hits_from_arrays(sp[:k], si[:k], pp[:k], pi[:k])

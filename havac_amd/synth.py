@@ -102,3 +102,63 @@ def plant_homologs(symbols: np.ndarray, consensus: np.ndarray, nreal: int, every
         planted += 1
         pos += every
     return planted
+
+
+# ---- synthetic FILES for the file-level API (Havac::loadSequence / loadPhmm) ---------------------
+
+def write_fasta(path: str, records, width: int = 60) -> None:
+    """records: iterable of (header, symbols-or-string).  Symbols 0..3 are written as ACGT."""
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    with open(path, "w") as f:
+        for header, seq in records:
+            if not isinstance(seq, str):
+                seq = letters[np.asarray(seq, dtype=np.uint8)].tobytes().decode()
+            f.write(f">{header}\n")
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width] + "\n")
+
+
+def emissions_from_consensus(consensus: np.ndarray, seed: int, lo: float = 0.80, hi: float = 0.97) -> np.ndarray:
+    """[L,4] match-emission file values (-ln p) of a Dfam-like model with the given consensus."""
+    rng = np.random.default_rng(seed)
+    L = consensus.size
+    pc = rng.uniform(lo, hi, size=L)
+    rest = rng.dirichlet(np.ones(3) * 4, size=L) * (1 - pc)[:, None]
+    p = np.empty((L, 4))
+    for k in range(L):
+        others = [a for a in range(4) if a != consensus[k]]
+        p[k, consensus[k]] = pc[k]
+        p[k, others] = rest[k]
+    return -np.log(p)
+
+
+def write_hmm(path: str, models, append: bool = False) -> None:
+    """models: iterable of dicts {name, acc, emissions [L,4] (-ln p), maxl, mu, lam}.  HMMER3/f ASCII."""
+    with open(path, "a" if append else "w") as f:
+        for m in models:
+            em = np.asarray(m["emissions"], dtype=np.float64)
+            L = em.shape[0]
+            f.write("HMMER3/f [3.1b2 | February 2015]\n")
+            f.write(f"NAME  {m['name']}\n")
+            if m.get("acc"):
+                f.write(f"ACC   {m['acc']}\n")
+            f.write(f"LENG  {L}\n")
+            f.write(f"MAXL  {m['maxl']}\n")
+            f.write("ALPH  DNA\nRF    no\nMM    no\nCONS  yes\nCS    no\nMAP   yes\n")
+            f.write("NSEQ  10\nEFFN  1.500000\nCKSUM 12345\n")
+            f.write(f"STATS LOCAL MSV      {m['mu']:9.4f} {m['lam']:8.5f}\n")
+            f.write(f"STATS LOCAL VITERBI  {m['mu'] - 0.8:9.4f} {m['lam']:8.5f}\n")
+            f.write(f"STATS LOCAL FORWARD  {m['mu'] + 5.0:9.4f} {m['lam']:8.5f}\n")
+            f.write("HMM          A        C        G        T   \n")
+            f.write("            m->m     m->i     m->d     i->m     i->i     d->m     d->d\n")
+            f.write("  COMPO   1.38629  1.38629  1.38629  1.38629\n")
+            f.write("          1.38629  1.38629  1.38629  1.38629\n")
+            f.write("          0.01005  5.29832  5.29832  0.61958  0.77255  0.00000        *\n")
+            for k in range(L):
+                vals = "  ".join("      *" if not np.isfinite(v) else f"{v:7.5f}" for v in em[k])
+                cons = "acgt"[int(np.argmin(em[k]))]
+                f.write(f"{k + 1:7d}   {vals} {k + 1:6d} {cons} - - -\n")
+                f.write("          1.38629  1.38629  1.38629  1.38629\n")
+                last = "        *" if k == L - 1 else "  0.95510"
+                f.write(f"          0.01005  5.29832  5.29832  0.61958  0.77255  0.48576{last}\n")
+            f.write("//\n")

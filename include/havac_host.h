@@ -1,0 +1,66 @@
+/*
+ * havac_host.h -- C entry points around the C++ `Havac` class (libhavac.so).
+ *
+ * The reference's public API is the C++ class in host/Havac.hpp:42-107; C++
+ * callers include havac_amd/csrc/host/Havac.hpp and use it directly.  These
+ * wrappers exist so that non-C++ callers (the pytest suite through ctypes, or
+ * any FFI) can drive the very same object, and so that the host-only stages
+ * (FASTA packing, model projection, hit resolution) can be tested without a GPU.
+ * Exceptions are turned into negative HAVAC_E_* codes (include/havac_dev.h).
+ */
+#ifndef HAVAC_HOST_H
+#define HAVAC_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct havac_host havac_host;
+
+/* Havac::Havac(deviceIndex, requiredPValue, xclbinSrc)  host/Havac.cpp:20-31 */
+int havac_host_create(uint32_t device_index, float required_p_value, havac_host **out);
+void havac_host_destroy(havac_host *h);
+int havac_host_load_sequence(havac_host *h, const char *fasta_path);   /* Havac::loadSequence  :57-77 */
+int havac_host_load_phmm(havac_host *h, const char *hmm_path);         /* Havac::loadPhmm      :42-55 */
+int havac_host_run(havac_host *h);                                     /* runHardwareClient    :80-83 */
+int havac_host_run_async(havac_host *h);                               /* runHardwareClientAsync :85-94 */
+int havac_host_wait(havac_host *h);                                    /* waitHardwareClientAsync :96-98 */
+int havac_host_abort(havac_host *h);                                   /* abortHardwareClient  :100-102 */
+int havac_host_state(havac_host *h);                                   /* currentHardwareState :190-192 */
+int havac_host_set_hit_capacity(havac_host *h, uint64_t max_hits);
+/* Havac::getHitsFromFinishedRun :145-187.  First call with cap = 0 to learn the count. */
+int havac_host_get_hits(havac_host *h, uint64_t *sequence_position, uint32_t *sequence_index,
+                        uint32_t *phmm_position, uint32_t *phmm_index, uint32_t cap, uint32_t *count);
+/* the raw 64-bit records the last get_hits call fetched from the device */
+int havac_host_get_raw_hits(havac_host *h, uint64_t *out, uint32_t cap, uint32_t *count);
+int havac_host_last_run_ms(havac_host *h, float *ssv_kernel_ms, float *total_ms);
+const char *havac_host_last_error(havac_host *h);
+
+/* ---- host-only stages, no device needed -------------------------------- */
+
+/* FastaVector + SequencePreprocessor: file -> 2-bit packed, segment-padded bytes.
+ * `seed` >= 0 calls srand(seed) first (ambiguity codes and record terminators
+ * draw from rand(), host/sequence/SequencePreprocessor.cpp:74,82). */
+int havac_host_pack_fasta(const char *fasta_path, int64_t seed, uint8_t *out, uint64_t cap, uint64_t *nbytes,
+                          uint64_t *nchars, uint32_t *nrecords);
+
+/* P7HmmReader + PhmmPreprocessor: file -> concatenated int8 [row][A,C,G,T]. */
+int havac_host_project_hmm(const char *hmm_path, float p_value, int8_t *out, uint64_t cap, uint64_t *nbytes,
+                           uint32_t *nmodels, uint32_t *model_lengths, uint32_t lengths_cap);
+
+/* findThreshold256ScalingFactor on explicit parameters (PhmmReprojection.cpp:36-64). */
+float havac_host_scaling_factor(float mu, float lambda, uint32_t max_length, uint32_t model_length, float p_value);
+/* emissionScoreToProjectedScore (PhmmReprojection.cpp:90-107). */
+float havac_host_project_score(float emission_score, float multiplier);
+
+/* The resolver alone: raw records + the two input files -> HavacHit fields. */
+int havac_host_resolve_hits(const char *fasta_path, const char *hmm_path, const uint64_t *raw, uint32_t nraw,
+                            uint64_t *sequence_position, uint32_t *sequence_index, uint32_t *phmm_position,
+                            uint32_t *phmm_index, uint32_t cap, uint32_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

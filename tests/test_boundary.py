@@ -1,0 +1,99 @@
+"""The drop-in boundary without a GPU: the C-ABI libraries load, export every symbol the headers
+declare, refuse to work without a device (no CPU fallback), and the product never touches oracle/."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+from havac_amd import _lib, havac
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(havac_[a-z0-9_]+)\s*\(", text)))
+
+
+def exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if " T " in line}
+
+
+def test_device_library_exports_everything_in_havac_dev_h():
+    names = declared_functions("havac_dev.h")
+    assert len(names) >= 20
+    have = exported(_lib.LIB_PATH)
+    assert not [n for n in names if n not in have]
+    assert sorted(_lib.SIGNATURES) == names            # the ctypes table covers the header, no more, no less
+    assert b"gfx950" in _lib.load().havac_dev_version()
+
+
+def test_host_library_exports_everything_in_havac_host_h():
+    names = declared_functions("havac_host.h")
+    have = exported(havac.HOST_LIB_PATH)
+    assert not [n for n in names if n not in have]
+    assert sorted(havac.HOST_SIGNATURES) == names
+    havac.load_host()
+
+
+def test_cpp_api_symbols_present():
+    """The C++ class keeps the reference's method names (host/Havac.hpp:42-107)."""
+    out = subprocess.run(["nm", "-DC", "--defined-only", havac.HOST_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for method in ("Havac::loadSequence", "Havac::loadPhmm", "Havac::runHardwareClient()", "Havac::runHardwareClientAsync",
+                   "Havac::waitHardwareClientAsync", "Havac::abortHardwareClient", "Havac::getHitsFromFinishedRun",
+                   "Havac::currentHardwareState", "HavacHit::toString", "SequencePreprocessor::SequencePreprocessor",
+                   "PhmmPreprocessor::PhmmPreprocessor", "p7HmmProjectForThreshold256", "findThreshold256ScalingFactor",
+                   "esl_gumbel_invsurv", "phmmPrefixSumsBinarySearch"):
+        assert method in out, method
+
+
+def test_code_object_is_gfx950_only():
+    """One offload bundle entry, for gfx950 (rocprim's host-side arch-name table is not a code object)."""
+    strings = subprocess.run(["strings", "-n", "6", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    targets = set(re.findall(r"hipv4-amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", strings))
+    assert targets == {"gfx950"}
+    assert "nvptx" not in strings and "sm_90" not in strings
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_cpu_fallback_without_a_device():
+    L = _lib.load()
+    h = C.c_void_p()
+    assert L.havac_dev_create(0, C.byref(h)) == _lib.E_NO_DEVICE
+    assert L.havac_ssv_ctx_create(C.byref(h)) == _lib.E_NO_DEVICE
+    from havac_amd.hw_client import HavacHwClient, NoDeviceError
+    with pytest.raises(NoDeviceError):
+        HavacHwClient()
+    with pytest.raises(NoDeviceError):
+        havac.Havac()
+
+
+def test_product_never_touches_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "havac_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".sh")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"(?m)^\s*(from|import)\s+oracle\b|pyoracle|liboracle|ssv_oracle|softssv_ref", text):
+                    bad.append(os.path.join(base, f))
+    assert not bad
+    for lib in (_lib.LIB_PATH, havac.HOST_LIB_PATH):
+        needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
+        assert "oracle" not in needed and "softssv" not in needed
+
+
+def test_shard_arithmetic_is_host_only():
+    """havac_ssv_shard_diagonals / shard_cells need no device: shards tile the diagonals exactly."""
+    from havac_amd.ssv import shard_cells, shard_diagonals
+    n, rows = 40 * 12288, 1000
+    for world in (1, 2, 3, 8):
+        spans = [shard_diagonals(n, rows, r, world) for r in range(world)]
+        assert spans[0][0] <= -(rows - 1) and spans[-1][1] >= n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        assert sum(shard_cells(n, rows, r, world) for r in range(world)) == n * rows
+        if world > 1:
+            cells = [shard_cells(n, rows, r, world) for r in range(world)]
+            assert max(cells) < 1.25 * min(cells)

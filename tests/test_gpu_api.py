@@ -1,0 +1,207 @@
+"""The reference's API surface on the GPU: HavacHwClient behaviours (host/HavacHwClient.cpp) and the
+file-level `Havac` class (host/Havac.cpp) end to end, checked against the CPU checker."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+from havac_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def client():
+    from havac_amd.hw_client import HavacHwClient
+    c = HavacHwClient(deviceIndex=0)
+    yield c
+    c.close()
+
+
+def small_inputs(nrows=200, nseg=2, seed=5):
+    model, cons = synth.dfam_like_model(nrows, seed)
+    sym = synth.random_symbols(nseg * synth.SEGMENT, seed + 1)
+    synth.plant_homologs(sym, cons, sym.size, every=5000, length=min(150, nrows))
+    return sym, model
+
+
+# ---- HavacHwClient argument checks, with the reference's exception types --------------------------
+
+def test_write_sequence_must_be_whole_segments(client):
+    from havac_amd.hw_client import LengthError
+    with pytest.raises(LengthError, match="multiple of the sequence segment length 12288"):
+        client.writeSequence(np.zeros(100, np.uint8))            # host/HavacHwClient.cpp:83-90
+
+
+def test_write_phmm_must_be_multiple_of_four(client):
+    from havac_amd.hw_client import LengthError
+    with pytest.raises(LengthError, match="not divisible by 4"):
+        client.writePhmm(np.zeros(7, np.int8))                   # host/HavacHwClient.cpp:113-119
+
+
+def test_run_needs_both_inputs(client):
+    from havac_amd.hw_client import LengthError
+    with pytest.raises(LengthError, match="sequence length in segments cannot be 0"):
+        client.invokeHavacSsvAsync()                             # host/HavacHwClient.cpp:142-144
+    client.writeSequence(np.zeros(synth.SEGMENT // 4, np.uint8))
+    with pytest.raises(LengthError, match="phmm length in vectors cannot be 0"):
+        client.invokeHavacSsvAsync()                             # :145-147
+
+
+def test_state_before_any_run_is_a_logic_error(client):
+    from havac_amd.hw_client import LogicError
+    with pytest.raises(LogicError, match="run object was not initialized"):
+        client.getHwState()                                      # host/HavacHwClient.cpp:163-170
+
+
+def test_async_run_states_and_rerun(client, oracle):
+    sym, model = small_inputs()
+    client.writeSequence(synth.pack_2bit(sym))
+    client.writePhmm(model)
+    client.invokeHavacSsvAsync()
+    assert client.getHwState() in (3, 4)                         # RUNNING or COMPLETED
+    assert client.waitForHavacSsvAsync() == 4
+    assert client.getHwState() == 4
+    want = oracle.ssv(sym, model)
+    first = client.getHitList()
+    assert np.array_equal(first, want)
+    assert client.getNumHits() == want.size
+    ssv_ms, total_ms = client.lastRunMs()
+    assert 0 < ssv_ms <= total_ms
+    # a second run on the same handle, new model, gives the new answer (buffers are reused)
+    model2, _ = synth.dfam_like_model(77, 99)
+    client.writePhmm(model2)
+    client.invokeHavacSsvAsync()
+    client.waitForHavacSsvAsync()
+    assert np.array_equal(client.getHitList(), oracle.ssv(sym, model2))
+
+
+def test_hit_buffer_overflow_is_reported(client, oracle):
+    from havac_amd.hw_client import HitOverflowError
+    sym = np.zeros(synth.SEGMENT, np.uint8)
+    model = np.full((9, 4), 127, np.int8)                         # a hit on every third row of every diagonal
+    want = oracle.ssv(sym, model)
+    client.setHitCapacity(1000)
+    client.writeSequence(synth.pack_2bit(sym))
+    client.writePhmm(model)
+    client.invokeHavacSsvAsync()
+    assert client.waitForHavacSsvAsync() == 5                     # ERROR
+    with pytest.raises(HitOverflowError):
+        client.getHitList()
+    client.setHitCapacity(want.size)                              # exactly enough
+    client.invokeHavacSsvAsync()
+    assert client.waitForHavacSsvAsync() == 4
+    assert np.array_equal(client.getHitList(), want)
+
+
+def test_dense_hits_every_cell_region(client, oracle):
+    """Every row +127 on all-A: a third of all cells hit; exercises the staging/flush path hard."""
+    sym = synth.random_symbols(2 * synth.SEGMENT, 3)
+    model = np.full((200, 4), 127, np.int8)
+    want = oracle.ssv_mt(sym, model)
+    client.setHitCapacity(want.size + 10)
+    client.writeSequence(synth.pack_2bit(sym))
+    client.writePhmm(model)
+    client.invokeHavacSsvAsync()
+    client.waitForHavacSsvAsync()
+    got = client.getHitList()
+    assert got.size == want.size and np.array_equal(got, want)
+
+
+def test_abort_and_timeout(client):
+    """A long run (about half a second of GPU work) is timed out on, then aborted (HavacHwClient.cpp:153-161)."""
+    model, _ = synth.dfam_like_model(120_000, 1)                  # 120k rows x 100 Mbp ~ 1.2e13 cells
+    packed = synth.random_packed(8139 * synth.SEGMENT, 2)
+    client.writeSequence(packed)
+    client.writePhmm(model)
+    client.invokeHavacSsvAsync()
+    t0 = time.time()
+    assert client.waitForHavacSsvAsync(timeout_ms=20) == 8        # TIMEOUT
+    assert client.getHwState() == 3                               # still RUNNING
+    assert client.abort() == 6                                    # ABORT
+    assert time.time() - t0 < 5.0
+    assert client.getHwState() == 6
+    # the handle is usable again afterwards
+    sym, small = small_inputs()
+    client.writeSequence(synth.pack_2bit(sym))
+    client.writePhmm(small)
+    client.invokeHavacSsvAsync()
+    assert client.waitForHavacSsvAsync() == 4
+
+
+# ---- the file-level Havac class --------------------------------------------------------------------
+
+def write_inputs(tmp_path, lengths, record_lengths, seed=0):
+    rng = np.random.default_rng(seed)
+    models, all_cons = [], []
+    for k, L in enumerate(lengths):
+        _, cons = synth.dfam_like_model(L, 70 + k + seed)
+        all_cons.append(cons)
+        models.append(dict(name=f"fam{k}", acc=f"RF{k:05d}", emissions=synth.emissions_from_consensus(cons, 80 + k),
+                           maxl=3 * L + 50, mu=-9.2 + 0.1 * k, lam=0.71))
+    cons = np.concatenate(all_cons)
+    records = []
+    for k, n in enumerate(record_lengths):
+        s = rng.integers(0, 4, size=n, dtype=np.uint8)
+        synth.plant_homologs(s, cons, n, every=4000, length=min(cons.size, 250), seed=k)
+        text = "".join("ACGT"[v] for v in s)
+        if k == 1 and n > 50:
+            text = text[:20] + "NNNNRYKM" + text[28:]             # ambiguity codes draw from rand()
+        records.append((f"seq{k}", text))
+    fa, hmm = tmp_path / "in.fa", tmp_path / "in.hmm"
+    synth.write_fasta(str(fa), records)
+    synth.write_hmm(str(hmm), models)
+    return str(fa), str(hmm)
+
+
+def test_havac_class_end_to_end(tmp_path, oracle):
+    from havac_amd import havac
+    fa, hmm = write_inputs(tmp_path, [60, 300, 150], [5000, 9000, 30000, 17])
+    libc = C.CDLL(None)
+    seed = 4242
+    packed, nchars, nrec = havac.pack_fasta(fa, seed=seed)        # what loadSequence will send, given the same srand
+    table, lens = havac.project_hmm(hmm, 0.02)
+    want_raw = oracle.ssv(oracle.unpack_2bit(packed), table)
+    assert want_raw.size > 20
+
+    h = havac.Havac(0, 0.02)
+    from havac_amd.hw_client import LogicError
+    with pytest.raises(LogicError, match="Phmm was not loaded"):
+        h.runHardwareClient()                                     # host/Havac.cpp:86-88
+    h.loadPhmm(hmm)
+    with pytest.raises(LogicError, match="Sequence was not loaded"):
+        h.runHardwareClientAsync()                                # :89-91
+    libc.srand(seed)
+    h.loadSequence(fa)
+    h.runHardwareClient()
+    assert h.currentHardwareState() == 4
+    hits = h.getHitsFromFinishedRun()
+    assert np.array_equal(h.rawHits(), want_raw)                  # device order, element for element
+    want = havac.resolve_hits(fa, hmm, want_raw)
+    assert hits == want
+    # every resolved hit points into a real record and a real model
+    ends = np.cumsum(lens)
+    for x in hits:
+        assert x.sequenceIndex < nrec and x.phmmIndex < len(lens) and x.phmmPosition < lens[x.phmmIndex]
+    # padding hits (beyond the last record) are dropped, nothing else
+    _, cols = oracle.unpack_hits(want_raw)
+    assert len(hits) == int((cols < nchars).sum())
+    with pytest.raises(RuntimeError):
+        h.loadPhmm(str(tmp_path / "missing.hmm"))
+    with pytest.raises(RuntimeError, match="Could not open fasta"):
+        h.loadSequence(str(tmp_path / "missing.fa"))
+    h.close()
+
+
+def test_havac_benchmark_binary(tmp_path):
+    """The counterpart of benchmark/benchmark.cpp runs and prints the reference's timing lines."""
+    import os
+    import subprocess
+    from havac_amd import havac
+    fa, hmm = write_inputs(tmp_path, [100], [20000], seed=3)
+    exe = os.path.join(os.path.dirname(havac.HOST_LIB_PATH), "havac_benchmark")
+    out = subprocess.run([exe, fa, hmm], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    for line in ("verified hits.", "havac build time", "havac load time", "havac run time", "havac verify time", "total time taken"):
+        assert line in out.stdout

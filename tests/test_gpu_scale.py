@@ -1,0 +1,107 @@
+"""Parity at BASELINE.json's shapes through size-independent properties: oracle windows with a left halo,
+shard unions, repeatability.  The oracle finishes each window in seconds."""
+import numpy as np
+import pytest
+
+from havac_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    return torch, torch.device("cuda", 0)
+
+
+def run_shards(torch, dev, packed, model, world=1, capacity=1 << 22):
+    """-> list of per-shard device-ordered record arrays (numpy uint64)"""
+    from havac_amd.ssv import SsvContext
+    ctx = SsvContext()
+    d_seq = torch.from_numpy(packed).to(dev)
+    d_phmm = torch.from_numpy(np.ascontiguousarray(model).reshape(-1)).to(dev)
+    hits = torch.empty(capacity, dtype=torch.int64, device=dev)
+    out = []
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for r in range(world):
+        ctx.enqueue(d_seq.data_ptr(), packed.size * 4, d_phmm.data_ptr(), model.shape[0], hits.data_ptr(), capacity, r, world, 0, stream)
+        n = ctx.finish()
+        out.append(hits[:n].cpu().numpy().view(np.uint64).copy())
+    ctx.close()
+    return out
+
+
+def check_windows(oracle, packed, model, got, windows):
+    rows, cols = oracle.unpack_hits(got)
+    nrows = model.shape[0]
+    for lo, hi in windows:
+        start = max(0, lo - (nrows - 1))
+        sym = synth.unpack_2bit(packed[start // 4: (hi + 3) // 4])        # start is a multiple of 4 below
+        want = oracle.ssv_window(sym, model, lo - start, hi - start)
+        wr, wc = oracle.unpack_hits(want)
+        want = oracle.pack_hits(wr, wc + np.uint64(start))
+        mine = got[(cols >= lo) & (cols < hi)]
+        assert np.array_equal(oracle.device_order(mine), oracle.device_order(want)), (lo, hi, mine.size, want.size)
+
+
+def test_c2_full_size_windows_and_repeatability(torch_dev, oracle):
+    """Config C2: L=1024 x 100,012,032 columns in one launch; exact check on windows spread over the matrix
+    (including both ends and segment boundaries), hit count plausibility, and run-to-run identity."""
+    torch, dev = torch_dev
+    model, cons = synth.dfam_like_model(1024, synth.SEED_MODEL)
+    packed = synth.random_packed(100_012_032, synth.SEED_SEQUENCE)
+    got = run_shards(torch, dev, packed, model)[0]
+    assert 500_000 < got.size < 2_000_000
+    assert np.array_equal(got, oracle.device_order(got))                   # already in device order
+    assert np.unique(got).size == got.size
+    n = 100_012_032
+    windows = [(0, 40_000), (n - 40_000, n), (12288 * 4000 - 20_000, 12288 * 4000 + 20_000)]
+    rng = np.random.default_rng(5)
+    windows += [(int(a) * 4, int(a) * 4 + 30_000) for a in rng.integers(1000, n // 4 - 10_000, size=5)]
+    check_windows(oracle, packed, model, got, windows)
+    again = run_shards(torch, dev, packed, model)[0]
+    assert np.array_equal(got, again)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_shard_union_equals_whole(torch_dev, oracle, world):
+    """The diagonal shards the multi-GPU path uses: their union is the single-launch answer, no duplicates."""
+    torch, dev = torch_dev
+    from havac_amd.ssv import shard_diagonals
+    model, cons = synth.model_collection([300, 50, 1200, 700], 31)
+    sym = synth.random_symbols(30 * synth.SEGMENT, 77)
+    synth.plant_homologs(sym, cons, sym.size, every=20_000, length=600)
+    packed = synth.pack_2bit(sym)
+    whole = run_shards(torch, dev, packed, model)[0]
+    want = oracle.ssv_mt(sym, model)
+    assert np.array_equal(whole, want)
+    parts = run_shards(torch, dev, packed, model, world=world)
+    for r, part in enumerate(parts):
+        rows, cols = oracle.unpack_hits(part)
+        lo, hi = shard_diagonals(sym.size, model.shape[0], r, world)
+        d = cols.astype(np.int64) - rows.astype(np.int64)
+        assert ((d >= lo) & (d < hi)).all()
+    assert np.array_equal(oracle.device_order(np.concatenate(parts)), whole)
+
+
+def test_c5_long_model_windows(torch_dev, oracle):
+    """Config C5 shape: one model of 20000 rows (far more than one wave tile is wide) x 10 Mbp; windows with
+    the full 19999-column halo."""
+    torch, dev = torch_dev
+    model, cons = synth.dfam_like_model(20000, 2005)
+    n = 814 * synth.SEGMENT
+    packed = synth.random_packed(n, 1005)
+    got = run_shards(torch, dev, packed, model, capacity=1 << 23)[0]
+    assert got.size > 100_000
+    check_windows(oracle, packed, model, got, [(0, 3000), (n - 3000, n), (5_000_000, 5_003_000)])
+
+
+def test_c3_many_models_windows(torch_dev, oracle):
+    """Config C3 shape scaled to what the oracle can check: 120 concatenated models (~60k rows) x 1.2 Mbp."""
+    torch, dev = torch_dev
+    lengths = synth.model_lengths(120)
+    model, cons = synth.model_collection(lengths, 2101)
+    n = 100 * synth.SEGMENT
+    packed = synth.random_packed(n, 1303)
+    got = run_shards(torch, dev, packed, model, capacity=1 << 23)[0]
+    check_windows(oracle, packed, model, got, [(0, 1500), (n - 1500, n), (600_000, 601_500)])

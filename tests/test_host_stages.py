@@ -1,0 +1,177 @@
+"""Host-only stages of the `Havac` API (no GPU): FASTA reader + 2-bit packer, HMMER3 reader +
+int8 projection, hit resolver.  These run on the CPU in the reference too (host/*.cpp)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from havac_amd import havac, synth
+
+
+@pytest.fixture(scope="module")
+def libc():
+    return C.CDLL(None)
+
+
+def rand_stream(libc, seed, n):
+    libc.srand(seed)
+    return [libc.rand() for _ in range(n)]
+
+
+# ---------------------------------------------------------------- FASTA + packing
+
+def test_fasta_records_terminators_and_padding(tmp_path, libc):
+    p = tmp_path / "a.fa"
+    p.write_text(">one desc\nACGT\nacgt\n\n>two\r\nGG\r\nTT\r\n>three\nA")
+    packed, nchars, nrec = havac.pack_fasta(str(p), seed=7)
+    assert nrec == 3
+    assert nchars == 8 + 1 + 4 + 1 + 1 + 1        # residues + one terminator per record (SequencePreprocessor.cpp:12)
+    assert packed.size == synth.SEGMENT // 4      # padded to one 12288-symbol segment
+    sym = synth.unpack_2bit(packed)
+    assert sym[:8].tolist() == [0, 1, 2, 3, 0, 1, 2, 3]
+    assert sym[9:13].tolist() == [2, 2, 3, 3]
+    assert sym[14] == 0
+    assert not sym[16:].any()                      # padding is symbol 0 = 'A' (SequencePreprocessor.cpp:41)
+    # terminators become random nucleotides: rand()%2 is drawn, discarded, then rand()%4 (:74,:82)
+    r = rand_stream(libc, 7, 6)
+    assert [int(sym[8]), int(sym[13]), int(sym[15])] == [r[1] % 4, r[3] % 4, r[5] % 4]
+
+
+def test_ambiguity_codes_follow_rand_call_order(tmp_path, libc):
+    p = tmp_path / "amb.fa"
+    p.write_text(">x\nRSWKMNBDHVrswkmn\n")
+    packed, nchars, _ = havac.pack_fasta(str(p), seed=11)
+    sym = synth.unpack_2bit(packed)[:nchars]
+    r = iter(rand_stream(libc, 11, 64))
+    want = []
+    for ch in "RSWKMNBDHVRSWKMN\0":
+        coin = next(r) % 2
+        want.append({"R": coin * 2, "S": coin + 1, "W": coin * 3, "K": coin + 2, "M": coin}.get(ch))
+        if want[-1] is None:
+            want[-1] = next(r) % 4
+    assert sym.tolist() == want
+
+
+def test_y_is_effectively_a(tmp_path):
+    """'Y' returns coin << 2 (0 or 4, SequencePreprocessor.cpp:77): the stray bit lands in the next
+    symbol's field and is cleared by that symbol's own write, so Y always packs as A."""
+    p = tmp_path / "y.fa"
+    p.write_text(">x\n" + "YT" * 50 + "\n")
+    for seed in range(4):
+        packed, nchars, _ = havac.pack_fasta(str(p), seed=seed)
+        sym = synth.unpack_2bit(packed)[:100]
+        assert sym[0::2].tolist() == [0] * 50 and sym[1::2].tolist() == [3] * 50
+
+
+def test_fasta_missing_file():
+    with pytest.raises(RuntimeError):
+        havac.pack_fasta("/nonexistent/none.fa")
+
+
+# ---------------------------------------------------------------- HMMER3 reader + projection
+
+def reference_scaling_factor(mu, lam, maxl, L, p):
+    """Independent numpy restatement of PhmmReprojection.cpp:36-64 with the same float/double widths."""
+    f32, f64 = np.float32, np.float64
+    mu, lam, maxl, L, p = f32(mu), f32(lam), f32(maxl), f32(L), f32(p)
+    pd = f64(p)
+    inner = (pd ** pd - 1) / pd if pd < 5e-9 else np.log(-1.0 * np.log(1.0 - pd))
+    inv = f64(mu) - inner / f64(lam)
+    n_loop = f32(np.log(f32(maxl / f32(maxl + f32(3)))))
+    n_loop_total = f32(n_loop * maxl)
+    n_escape = f32(np.log(f32(f32(3) / f32(maxl + f32(3)))))
+    b_mk = f32(np.log(f32(f32(2) / f32(L * f32(L + f32(1))))))
+    e_c = f32(np.log(f32(0.5)))
+    core = f32(f32(f32(f32(n_escape + n_loop_total) + n_escape) + b_mk) + e_c)
+    bg_p = f32(maxl / f32(maxl + f32(1)))
+    bg_total = f32(maxl * f32(np.log(bg_p)))
+    bg_move = f32(np.log(f64(1.0) - f64(bg_p)))
+    bg = f32(bg_total + bg_move)
+    ln2 = f64(0.69314718055994529)
+    thr_nats = f32(inv * ln2 + f64(bg) - f64(core))
+    thr_bits = f32(f64(thr_nats) / ln2)
+    return f32(f32(256) / thr_bits)
+
+
+@pytest.mark.parametrize("mu,lam,maxl,L,p", [(-9.0, 0.72, 400, 100, 0.02), (-8.3, 0.70, 1300, 1024, 0.02),
+                                             (-10.1, 0.69, 25000, 20000, 0.05), (-7.5, 0.71, 120, 50, 1e-4),
+                                             (-9.0, 0.72, 400, 100, 1e-10)])
+def test_scaling_factor_widths(mu, lam, maxl, L, p):
+    got = havac.scaling_factor(mu, lam, maxl, L, p)
+    want = float(reference_scaling_factor(mu, lam, maxl, L, p))
+    assert got == pytest.approx(want, rel=2e-6)     # logf vs numpy's log on float32 may differ in the last ulp
+
+
+def test_worked_example_of_the_survey():
+    """L=100, MAXL=400, mu=-9, lambda=0.72, p=0.02 -> scale ~14.2, a 2-bit match ~ +28,
+    a -ln p = 3 mismatch ~ -33."""
+    s = havac.scaling_factor(-9.0, 0.72, 400, 100, 0.02)
+    assert 14.0 < s < 14.4
+    assert 256.0 / s == pytest.approx(18.1, abs=0.3)        # threshold in bits
+    assert havac.project_score(0.0, s) == round(2 * s)       # p = 1 -> 2 bits over the 1/4 background
+    assert havac.project_score(3.0, s) in (-33.0, -32.0, -34.0)
+    assert havac.project_score(50.0, s) == -128.0 and havac.project_score(-50.0, s) == 127.0   # saturation
+    assert havac.project_score(float("inf"), s) == -128.0   # '*' in the file
+
+
+def test_hmm_reader_and_projection_of_a_collection(tmp_path):
+    lengths = [50, 200, 77]
+    models, tables = [], []
+    for k, L in enumerate(lengths):
+        _, cons = synth.dfam_like_model(L, 40 + k)
+        em = synth.emissions_from_consensus(cons, 50 + k)
+        if k == 1:
+            em[3, 2] = np.inf                                # a '*' entry
+        mu, lam, maxl = -9.0 + 0.3 * k, 0.70 + 0.01 * k, 4 * L + 10
+        models.append(dict(name=f"m{k}", acc=f"RF{k:05d}", emissions=em, maxl=maxl, mu=mu, lam=lam))
+        scale = np.float32(havac.scaling_factor(mu, lam, maxl, L, 0.02))
+        s = np.float32(np.round(em, 5).astype(np.float32))   # the file carries 5 decimals
+        alpha, beta = np.float32(2) * scale, np.float32(1.44269504089) * scale
+        y = np.float32(alpha - np.float32(s * beta))
+        y = np.where(np.isfinite(y), np.sign(y) * np.floor(np.abs(y) + np.float32(0.5)), -128)   # round half away
+        tables.append(np.clip(y, -128, 127).astype(np.int8))
+    path = tmp_path / "c.hmm"
+    synth.write_hmm(str(path), models)
+    got, lens = havac.project_hmm(str(path), 0.02)
+    assert lens.tolist() == lengths
+    want = np.concatenate(tables)                             # back to back, no separator (PhmmPreprocessor.cpp:9-31)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+    assert got[50 + 3, 2] == -128
+
+
+def test_hmm_format_errors(tmp_path):
+    bad = tmp_path / "bad.hmm"
+    bad.write_text("this is not a profile\n")
+    with pytest.raises(RuntimeError):
+        havac.project_hmm(str(bad))
+    with pytest.raises(RuntimeError):
+        havac.project_hmm(str(tmp_path / "missing.hmm"))
+    _, cons = synth.dfam_like_model(10, 1)
+    trunc = tmp_path / "trunc.hmm"
+    synth.write_hmm(str(trunc), [dict(name="t", acc="", emissions=synth.emissions_from_consensus(cons, 2), maxl=50, mu=-9, lam=0.7)])
+    text = trunc.read_text().splitlines()
+    trunc.write_text("\n".join(text[:-8]) + "\n")            # cut inside the body, no "//"
+    with pytest.raises(RuntimeError):
+        havac.project_hmm(str(trunc))
+
+
+# ---------------------------------------------------------------- resolver
+
+def test_resolver_maps_records_to_hits(tmp_path, oracle):
+    fa, hmm = tmp_path / "r.fa", tmp_path / "r.hmm"
+    synth.write_fasta(str(fa), [("a", np.zeros(100, np.uint8)), ("b", np.ones(20000, np.uint8)), ("c", np.zeros(7, np.uint8))])
+    models = []
+    for k, L in enumerate([30, 40]):
+        _, cons = synth.dfam_like_model(L, k)
+        models.append(dict(name=f"m{k}", acc="", emissions=synth.emissions_from_consensus(cons, k), maxl=200, mu=-9, lam=0.7))
+    synth.write_hmm(str(hmm), models)
+    # global columns: a = [0,100] (terminator at 100), b = [101, 20101], c = [20102, 20109]; then padding
+    rows = [0, 29, 30, 69, 5, 5, 5, 10]
+    cols = [0, 100, 101, 20101, 20102, 20108, 20109, 20110]      # the last one is padding -> dropped
+    raw = oracle.pack_hits(rows, cols)
+    hits = havac.resolve_hits(str(fa), str(hmm), raw)
+    got = [(h.sequencePosition, h.sequenceIndex, h.phmmPosition, h.phmmIndex) for h in hits]
+    assert got == [(0, 0, 0, 0), (100, 0, 29, 0), (0, 1, 0, 1), (20000, 1, 39, 1), (0, 2, 5, 0), (6, 2, 5, 0), (7, 2, 5, 0)]
+    assert hits[1].toString() == "sequence $0, position 100; phmm #0 position 29"
