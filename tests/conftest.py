@@ -4,6 +4,8 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- first, on purpose: torch ships its own libamdhip64; whichever HIP runtime is
+              # loaded first owns the GPU for the process, and libhavac_dev.so binds to the one already loaded
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -35,8 +35,8 @@ def check_windows(oracle, packed, model, got, windows):
     rows, cols = oracle.unpack_hits(got)
     nrows = model.shape[0]
     for lo, hi in windows:
-        start = max(0, lo - (nrows - 1))
-        sym = synth.unpack_2bit(packed[start // 4: (hi + 3) // 4])        # start is a multiple of 4 below
+        start = max(0, lo - (nrows - 1)) // 4 * 4                         # whole packed bytes; a longer halo is harmless
+        sym = synth.unpack_2bit(packed[start // 4: (hi + 3) // 4])[: hi - start]
         want = oracle.ssv_window(sym, model, lo - start, hi - start)
         wr, wc = oracle.unpack_hits(want)
         want = oracle.pack_hits(wr, wc + np.uint64(start))
