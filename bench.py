@@ -149,11 +149,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # HAVAC_BENCH_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the N>1 path on a 1-GPU box
+    # (RCCL refuses two ranks on one device); the driver's real multi-GPU runs use the default, nccl = RCCL.
+    backend = os.environ.get("HAVAC_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     assert args.columns_per_gpu % synth.SEGMENT == 0
     ncols = args.columns_per_gpu * world
@@ -192,7 +200,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -215,11 +223,12 @@ def main():
             "vs_baseline": round(gcups / FPGA_GCUPS, 3), "dtype": "i16 (packed pairs over int8 scores)",
             "data": "synthetic",
             "config": {
-                "workload": f"C2: 1 pHMM L={nrows} x {args.columns_per_gpu} columns per GPU (100 Mbp padded to 12288), "
-                            "int8 SSV, one kernel launch per step",
+                "workload": (("C2: " if (nrows == ROWS and args.columns_per_gpu == COLUMNS_PER_GPU) else "custom: ") +
+                             f"1 pHMM L={nrows} x {args.columns_per_gpu} columns per GPU "
+                             "(C2 = 100 Mbp padded to 12288), int8 SSV, one kernel launch per step"),
                 "rows": nrows, "columns": ncols, "cells_per_step": total_cells, "hits_per_step": nhits,
                 "planted_homologs": planted,
-                "parallelism": f"diagonal-sharded x{world}" + (", RCCL all_gather of hit records" if world > 1 else ""),
+                "parallelism": f"diagonal-sharded x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} all_gather of hit records" if world > 1 else ""),
                 "baseline": "1739 GCUPS = reference README.md:4, 1x Alveo U50 FPGA",
             },
             "kernel": {"name": "ssv_diag_kernel", "avg_ms": round(ssv_ms, 4), "enqueue_to_ordered_ms": round(enq_ms, 4),

@@ -20,21 +20,24 @@ def gather_hits(local_hits: torch.Tensor, local_count: int, group=None):
     all_gather of the records padded to the largest count (payload is KB..MB)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    dev = local_hits.device
+    out_dev = local_hits.device
+    # gloo (CPU rehearsals and the tests) moves host tensors; nccl = RCCL moves device tensors over xGMI
+    dev = torch.device("cpu") if dist.get_backend(group) == "gloo" else out_dev
+    local_hits = local_hits[:local_count].to(dev)
     mine = torch.tensor([local_count], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts, mine, group=group)
     counts = [int(c.item()) for c in counts]
     biggest = max(counts)
     if biggest == 0:
-        return (local_hits[:0].clone() if rank == 0 else None), counts
+        return (local_hits[:0].to(out_dev) if rank == 0 else None), counts
     padded = torch.zeros(biggest, dtype=local_hits.dtype, device=dev)
     padded[:local_count] = local_hits[:local_count]
     parts = [torch.empty(biggest, dtype=local_hits.dtype, device=dev) for _ in range(world)]
     dist.all_gather(parts, padded, group=group)
     if rank != 0:
         return None, counts
-    return torch.cat([p[:c] for p, c in zip(parts, counts)]), counts
+    return torch.cat([p[:c] for p, c in zip(parts, counts)]).to(out_dev), counts
 
 
 class ShardedSsv:

@@ -1,0 +1,83 @@
+"""The N>1 path on CPU: world_size-2 (and 3) gloo groups run havac_amd.dist.gather_hits on shards.
+
+No GPU here, and the product has no CPU compute path, so each rank's shard of hits is produced by the
+CPU checker (test infrastructure) filtered to the diagonals havac_ssv_shard_diagonals assigns to that
+rank -- exactly the records the rank's GPU would report (tests/test_gpu_scale.py proves that on the GPU).
+What is under test is everything after the kernel: shard arithmetic, the two collectives, the merge."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def worker(rank, world, port, case, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from havac_amd import synth
+    from havac_amd.dist import gather_hits
+    from havac_amd.ssv import shard_diagonals
+    from oracle import pyoracle as O
+
+    if case == "empty":
+        model = np.full((40, 4), -128, np.int8)
+        sym = synth.random_symbols(synth.SEGMENT, 1)
+    elif case == "lopsided":               # all hits on diagonals of the last shard
+        model, cons = synth.dfam_like_model(300, 3)
+        sym = synth.random_symbols(6 * synth.SEGMENT, 4)
+        sym[: 5 * synth.SEGMENT] = 0
+        model[:, 0] = -100
+    else:
+        model, cons = synth.model_collection([200, 900, 64], 11)
+        sym = synth.random_symbols(12 * synth.SEGMENT, 12)
+        synth.plant_homologs(sym, cons, sym.size, every=9000, length=500)
+    whole = O.ssv(sym, model)
+    rows, cols = O.unpack_hits(whole)
+    lo, hi = shard_diagonals(sym.size, model.shape[0], rank, world)
+    d = cols.astype(np.int64) - rows.astype(np.int64)
+    mine = whole[(d >= lo) & (d < hi)]
+    rng = np.random.default_rng(rank)
+    mine = mine[rng.permutation(mine.size)]                     # arrival order inside a shard is arbitrary
+    cap = max(8, mine.size + 5)
+    local = torch.zeros(cap, dtype=torch.int64)
+    local[: mine.size] = torch.from_numpy(mine.view(np.int64))
+    merged, counts = gather_hits(local, int(mine.size))
+    assert counts[rank] == mine.size and sum(counts) == whole.size
+    if rank == 0:
+        got = O.device_order(merged.numpy().view(np.uint64))     # rank 0's final ordering (GPU: havac_ssv_sort_hits)
+        np.save(out_path, np.array([int(np.array_equal(got, whole)), whole.size, max(counts), min(counts)]))
+    else:
+        assert merged is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "mixed"), (3, "mixed"), (2, "empty"), (2, "lopsided")])
+def test_gather_of_shards_over_gloo(tmp_path, oracle, world, case):
+    out = str(tmp_path / "result.npy")
+    mp.spawn(worker, args=(world, free_port(), case, out), nprocs=world, join=True)
+    ok, total, most, least = np.load(out)
+    assert ok == 1
+    if case == "empty":
+        assert total == 0
+    if case == "mixed":
+        assert total > 50 and least > 0
+    if case == "lopsided":
+        assert total > 0 and least == 0
