@@ -316,8 +316,9 @@ struct havac_dev {
     uint8_t* d_seq = nullptr; uint64_t seq_bytes = 0; uint64_t seq_alloc = 0;
     int8_t* d_phmm = nullptr; uint64_t phmm_bytes = 0; uint64_t phmm_alloc = 0;
     uint64_t* d_hits = nullptr; uint64_t hit_capacity = 0;
-    uint32_t* h_abort = nullptr;        // pinned, mapped: the kernel polls it
-    uint32_t* d_abort = nullptr;
+    uint32_t* d_abort = nullptr;        // device word the kernel polls (cache-bypassing loads)
+    hipStream_t abort_stream = nullptr; // abort() writes the word from here while the kernel runs
+    bool abort_requested = false;
     hipEvent_t done = nullptr;
     bool has_run = false, finished = false, aborted = false, failed = false;
     uint64_t found = 0;
@@ -348,9 +349,9 @@ extern "C" int havac_dev_create(uint32_t device_index, havac_dev** out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(HAVAC_E_NO_DEVICE);   // the code object is gfx950 only
     if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) return fail(HAVAC_E_RUNTIME);
     if (havac_ssv_ctx_create(&d->ctx) != HAVAC_OK) return fail(HAVAC_E_RUNTIME);
-    if (hipHostMalloc(&d->h_abort, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return fail(HAVAC_E_NOMEM);
-    *d->h_abort = 0;
-    if (hipHostGetDevicePointer((void**)&d->d_abort, d->h_abort, 0) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+    if (hipStreamCreateWithFlags(&d->abort_stream, hipStreamNonBlocking) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+    if (hipMalloc(&d->d_abort, sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_NOMEM);
+    if (hipMemset(d->d_abort, 0, sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_RUNTIME);
     if (hipEventCreateWithFlags(&d->done, hipEventDisableTiming) != hipSuccess) return fail(HAVAC_E_RUNTIME);
     if (dev_alloc_hits(d, kDefaultHitCapacity) != HAVAC_OK) return fail(HAVAC_E_NOMEM);
     *out = d;
@@ -365,7 +366,8 @@ extern "C" void havac_dev_destroy(havac_dev* d) {
     if (d->d_seq) (void)hipFree(d->d_seq);
     if (d->d_phmm) (void)hipFree(d->d_phmm);
     if (d->d_hits) (void)hipFree(d->d_hits);
-    if (d->h_abort) (void)hipHostFree(d->h_abort);
+    if (d->d_abort) (void)hipFree(d->d_abort);
+    if (d->abort_stream) (void)hipStreamDestroy(d->abort_stream);
     if (d->done) (void)hipEventDestroy(d->done);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
@@ -437,7 +439,8 @@ extern "C" int havac_dev_run_async(havac_dev* d) {
     if (d->phmm_bytes == 0) { d->err = "phmm length in vectors cannot be 0, but 0 was given to the client."; return HAVAC_E_LENGTH; }
     if (d->has_run && !d->finished) { d->err = "a run is already in flight"; return HAVAC_E_LOGIC; }
     HIP_TRY(d->err, hipSetDevice(d->device));
-    *d->h_abort = 0;
+    HIP_TRY(d->err, hipMemsetAsync(d->d_abort, 0, sizeof(uint32_t), d->stream));
+    d->abort_requested = false;
     d->aborted = false; d->failed = false; d->finished = false; d->found = 0;
     int rc = havac_ssv_enqueue(d->ctx, d->d_seq, d->seq_bytes * 4, d->d_phmm, (uint32_t)(d->phmm_bytes / 4), 0, 1,
                                d->d_hits, d->hit_capacity, d->d_abort, d->stream);
@@ -454,7 +457,7 @@ static int dev_finish(havac_dev* d) {
     int rc = havac_ssv_finish(d->ctx, &found);
     d->finished = true;
     d->found = found;
-    d->aborted = (*d->h_abort != 0);
+    d->aborted = d->abort_requested;
     if (rc != HAVAC_OK) {
         d->err = havac_ssv_ctx_last_error(d->ctx);
         d->failed = true;
@@ -500,9 +503,11 @@ extern "C" int havac_dev_abort(havac_dev* d) {
     if (!d->has_run) { d->err = "no run to abort"; return HAVAC_E_LOGIC; }
     if (d->finished) return havac_dev_state(d);
     if (hipEventQuery(d->done) == hipSuccess) return dev_finish(d);
-    *d->h_abort = 1;
-    __sync_synchronize();
-    hipError_t e = hipEventSynchronize(d->done);
+    static const uint32_t one = 1;
+    d->abort_requested = true;
+    hipError_t e = hipMemcpyAsync(d->d_abort, &one, sizeof one, hipMemcpyHostToDevice, d->abort_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->abort_stream);
+    if (e == hipSuccess) e = hipEventSynchronize(d->done);
     if (e != hipSuccess) { d->err = hip_msg("hipEventSynchronize", e); d->finished = true; d->failed = true; return HAVAC_STATE_ERROR; }
     return dev_finish(d);
 }

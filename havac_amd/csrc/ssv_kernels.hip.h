@@ -290,7 +290,9 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
     expand(p_lo, 16);
 
     for (int64_t p0 = p_lo; p0 < p_hi; p0 += kChunkRows) {
-        if (abort_flag && ((p0 & 2047) == 0) &&
+        // abort: a device word, read past the caches every 2048 rows (never on a wave's first chunk, so
+        // short models pay nothing)
+        if (abort_flag && ((p0 & 2047) == 0) && p0 != p_lo &&
             __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
         // rows of the chunk: fetched in two batches of scalar loads, the second lands while rows 0..15 run
         const const_rows_t rows = (const_rows_t)(const row16_t*)(rows16 + p0);
