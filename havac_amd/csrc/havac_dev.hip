@@ -104,7 +104,7 @@ uint64_t cells_below_diag(uint64_t nsymbols, uint32_t nrows, int64_t D) {
 // ===========================================================================
 struct havac_ssv_ctx {
     int device = 0;
-    uint2* rows16 = nullptr; size_t rows16_rows = 0;
+    uint32_t* rows8 = nullptr; size_t rows8_rows = 0;   // padded copy of the model
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     uint64_t* sort_alt = nullptr; size_t sort_alt_count = 0;
     unsigned long long* d_count = nullptr;
@@ -141,7 +141,7 @@ extern "C" int havac_ssv_ctx_create(havac_ssv_ctx** out) {
 
 extern "C" void havac_ssv_ctx_destroy(havac_ssv_ctx* c) {
     if (!c) return;
-    if (c->rows16) (void)hipFree(c->rows16);
+    if (c->rows8) (void)hipFree(c->rows8);
     if (c->sort_tmp) (void)hipFree(c->sort_tmp);
     if (c->sort_alt) (void)hipFree(c->sort_alt);
     if (c->d_count) (void)hipFree(c->d_count);
@@ -209,24 +209,24 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     HIP_TRY(c->err, hipSetDevice(c->device));
 
     Tiling t = make_tiling(nsymbols, nrows);
-    if (c->rows16_rows < t.nrows_padded) {
-        if (c->rows16) (void)hipFree(c->rows16);
-        c->rows16 = nullptr; c->rows16_rows = 0;
-        HIP_TRY(c->err, hipMalloc(&c->rows16, (size_t)t.nrows_padded * sizeof(uint2)));
-        c->rows16_rows = t.nrows_padded;
+    if (c->rows8_rows < t.nrows_padded) {
+        if (c->rows8) (void)hipFree(c->rows8);
+        c->rows8 = nullptr; c->rows8_rows = 0;
+        HIP_TRY(c->err, hipMalloc(&c->rows8, (size_t)t.nrows_padded * sizeof(uint32_t)));
+        c->rows8_rows = t.nrows_padded;
     }
     uint32_t tb, te;
     shard_tiles(t, nsymbols, shard_index, shard_count, &tb, &te);
 
     HIP_TRY(c->err, hipEventRecord(c->ev[0], stream));
     HIP_TRY(c->err, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), stream));
-    hipLaunchKernelGGL(ssv_expand_model, dim3((t.nrows_padded + 255) / 256), dim3(256), 0, stream,
-                       d_phmm, nrows, c->rows16, t.nrows_padded);
+    hipLaunchKernelGGL(ssv_pad_model, dim3((t.nrows_padded + 255) / 256), dim3(256), 0, stream,
+                       d_phmm, nrows, c->rows8, t.nrows_padded);
     HIP_TRY(c->err, hipEventRecord(c->ev[1], stream));
     if (te > tb) {
         uint32_t nblocks = (te - tb + kWavesPerBlock - 1) / kWavesPerBlock;
         hipLaunchKernelGGL(ssv_diag_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream,
-                           d_sequence, (int64_t)nsymbols, (const uint2*)c->rows16, t.nrows_padded, t.first_diag,
+                           d_sequence, (int64_t)nsymbols, (const uint32_t*)c->rows8, t.nrows_padded, t.first_diag,
                            tb, te, d_hits, c->d_count, hit_capacity, d_abort_flag);
     }
     HIP_TRY(c->err, hipEventRecord(c->ev[2], stream));

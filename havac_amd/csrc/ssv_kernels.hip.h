@@ -12,26 +12,36 @@
 //    and its scores never move.  No inter-lane shuffle, no inter-tile carry
 //    (the FPGA's scoreQueue, device/HavacHls.cpp:451-465, disappears) and no
 //    halo between GPUs.  A wave owns 64 x 32 = 2048 diagonals (a "tile").
-//  * TWO CELLS PER VGPR as packed int16 holding (score - 32768): one
-//    v_pk_add_i16 with clamp is add + clamp-at-zero, and a crossing of 256 is
-//    bit 8 of the unbiased score (scores never exceed 255 + 127).
-//  * MATCH SCORES BY v_perm_b32.  The model row is widened once to four int16
-//    (8 bytes, {A,C | G,T}); the 2-bit symbols of a diagonal pair are expanded
-//    once per 32-row chunk into a byte selector [2a,2a+1,2b,2b+1], so one
-//    v_perm_b32 yields both sign-extended match scores.  The symbol window
-//    slides one position per row; even rows use the aligned selector words,
-//    odd rows the words shifted by 16 bits (v_alignbit), both indexed
-//    statically in the fully unrolled 32-row chunk, so the slide costs nothing.
+//  * TWO CELLS PER VGPR as packed int16 holding (256*score - 32768).  With that
+//    scale and bias one v_pk_add_i16 with clamp does everything the FPGA's cell
+//    does (device/HavacHls.cpp:370-386): saturation at -32768 IS the clamp at
+//    score 0, and saturation at +32767 IS the threshold: score + match >= 256
+//    exactly when the sum leaves the int16 range.  Every regular value is a
+//    multiple of 256, so a crossed cell is recognisable afterwards by a non-zero
+//    low byte (0x7fff), and it stays recognisable for at least one more row
+//    (0x7fff + 256*m keeps the low byte unless it saturates again at the top).
+//    That is why hits are looked for only once per PAIR of rows.
+//  * MATCH SCORES BY v_perm_b32 straight from the reference's int8 row word: the
+//    selector of a diagonal pair with symbols (a,b) is the byte pattern
+//    [0x0c, a, 0x0c, b] (0x0c selects the constant 0x00), which yields
+//    (M[a] << 8) | (M[b] << 24): both match scores, already multiplied by 256.
+//    The 2-bit symbols are expanded into selectors once per 32-row chunk through
+//    an LDS table.  The symbol window slides one position per row; even rows use
+//    the aligned selector words, odd rows the words shifted by 16 bits, both
+//    indexed statically in the fully unrolled chunk, so the slide costs nothing.
 //  * OUTSIDE THE MATRIX (columns < 0 or >= N, rows >= nrows) the selector
-//    / row yields a large negative score, which pins the cell at 0 and can
-//    never hit: no per-cell predicate anywhere in the hot loop.
-//  * HITS are rare (about 1e-5 per cell on Dfam-like models): the 16 score
-//    registers are OR-ed, one wave-wide test per row finds bit 8, and only then
-//    the slow path emits and resets.  Records are appended through one atomic
-//    per wave-row and ordered afterwards (ssv_order_* below).
+//    / row yields a negative score, which pins the cell at 0 and can never hit:
+//    no per-cell predicate anywhere in the hot loop.
+//  * HITS are rare (about 1e-5 per cell on Dfam-like models): after each row pair
+//    the 16 score registers are OR-ed and one wave-wide test looks at the low
+//    bytes; only then the slow path sorts out which row crossed, repairs the
+//    second row for cells that crossed on the first (they restart from 0,
+//    test/softSsv/SoftSsv.cpp:43-44), and parks one mask per row in LDS.
+//    Records leave through LDS staging with one atomic per burst and are put in
+//    the FPGA's order afterwards.
 //
-// Roofline: integer VALU issue; HBM traffic is
-// N/4 + 8*rows bytes per tile sweep, thousands of cells per byte.
+// Roofline: integer VALU issue; HBM
+// traffic is N/4 + 4*rows + 8*hits bytes per launch, thousands of cells per byte.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,9 +54,10 @@ constexpr int kRegs = kDiagsPerLane / 2;
 constexpr int kTileDiags = 64 * kDiagsPerLane;    // one wave
 constexpr int kChunkRows = 32;                    // rows per unrolled chunk
 constexpr int kWavesPerBlock = 4;
-constexpr uint32_t kScoreZero = 0x80008000u;      // two cells at score 0 (bias -32768)
-constexpr uint32_t kHitBits = 0x01000100u;        // bit 8 of either unbiased score
-constexpr uint32_t kPadSelector = 0x0d0c0d0cu;    // v_perm: bytes (0x00,0xFF) -> int16 -256 twice
+constexpr uint32_t kScoreZero = 0x80008000u;      // two cells at score 0: 256*0 - 32768
+constexpr uint32_t kCrossedBits = 0x00010001u;    // bit 0 of either cell: set only in 0x7fff-derived values
+constexpr uint32_t kPadSelector = 0x0d0c0d0cu;    // v_perm: bytes (0x00,0xff) -> 0xff00 = score -1, twice
+constexpr uint32_t kPadRow = 0x80808080u;         // a row past the model: -128 for every symbol
 
 // sort key of a hit: (segment, row, column-in-segment) -- the FPGA's emission
 // order (device/HavacHls.cpp:151-152,264; device/HitReporting.cpp:178-337)
@@ -71,24 +82,14 @@ __device__ __forceinline__ uint64_t record_to_key(uint64_t rec) {
 }
 
 // ---------------------------------------------------------------------------
-// model int8 [row][A,C,G,T]  ->  int16 x4 per row, padded with rows of -128 up
-// to a whole number of chunks (a padding row can only lower a score).
-// Replaces nothing in the reference: the FPGA muxes bytes directly
-// (device/HavacHls.cpp:429-442); this is the layout v_perm_b32 wants.
-__global__ void ssv_expand_model(const int8_t* __restrict__ phmm, uint32_t nrows,
-                                 uint2* __restrict__ rows16, uint32_t nrows_padded) {
+// model int8 [row][A,C,G,T] -> the same words, padded with rows of -128 up to a
+// whole number of chunks (a padding row can only lower a score).  The kernel
+// reads the copy through the constant address space.
+__global__ void ssv_pad_model(const int8_t* __restrict__ phmm, uint32_t nrows,
+                              uint32_t* __restrict__ rows8, uint32_t nrows_padded) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrows_padded) return;
-    int a = -128, c = -128, g = -128, t = -128;
-    if (r < nrows) {
-        uint32_t w = reinterpret_cast<const uint32_t*>(phmm)[r];
-        a = (int8_t)(w & 0xff); c = (int8_t)((w >> 8) & 0xff);
-        g = (int8_t)((w >> 16) & 0xff); t = (int8_t)(w >> 24);
-    }
-    uint2 o;
-    o.x = ((uint32_t)a & 0xffffu) | ((uint32_t)c << 16);
-    o.y = ((uint32_t)g & 0xffffu) | ((uint32_t)t << 16);
-    rows16[r] = o;
+    rows8[r] = r < nrows ? reinterpret_cast<const uint32_t*>(phmm)[r] : kPadRow;
 }
 
 // ---------------------------------------------------------------------------
@@ -100,12 +101,12 @@ __device__ __forceinline__ uint32_t sat_add_pk16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, r);
 }
 
-// selector word for the symbol pair in bits [3:0] of `nib`: bytes
-// [2a, 2a+1, 2b, 2b+1] (a = low symbol)
+// selector word for the two symbols in bits [shift+3 : shift] of w: bytes
+// [0x0c, a, 0x0c, b] (a = low symbol) -> v_perm gives (row[a] << 8) | (row[b] << 24)
 __device__ __forceinline__ uint32_t pair_selector(uint32_t w, int shift) {
     uint32_t a = (w >> shift) & 3u;
     uint32_t b = (w >> (shift + 2)) & 3u;
-    return ((b * 0x0202u) << 16) + (a * 0x0202u + 0x01000100u);   // 24-bit multiplies + v_lshl_add
+    return 0x000c000cu | (a << 8) | (b << 24);
 }
 
 // 8 bytes = 32 symbols at symbol offset `pos` (multiple of 32); zero outside the buffer
@@ -153,8 +154,9 @@ __device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t sta
 }
 
 // Once per chunk, only if some row of the chunk parked masks.  `rows_with_hits`
-// has bit r set for row p0 + r.  The column of bit b of lane l on row p0 + r is
-// wave_column0 + r + 32*l + b.  Returns the new number of staged records.
+// has bit r set for row p0 + r.  Bit q of lane l's mask is the lane's diagonal
+// 4*(q & 7) + (q >> 3) (see crossed_mask), whose column on row p0 + r is
+// wave_column0 + r + 32*l + that.  Returns the new number of staged records.
 __device__ __noinline__ uint32_t drain_rows(const HitSink sink, uint32_t staged, uint32_t rows_with_hits, uint32_t p0,
                                             int64_t wave_column0, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -169,7 +171,8 @@ __device__ __noinline__ uint32_t drain_rows(const HitSink sink, uint32_t staged,
             const uint32_t m = __builtin_amdgcn_readlane(mask, src);
             if (lane < 32 && ((m >> lane) & 1u)) {
                 const uint32_t pos = staged + __popc(m & ((1u << lane) - 1u));
-                sink.stage[pos] = hit_key(p0 + r, (uint64_t)(wave_column0 + r + 32 * src + lane));
+                const int diagonal = 4 * (lane & 7) + (lane >> 3);
+                sink.stage[pos] = hit_key(p0 + r, (uint64_t)(wave_column0 + r + 32 * src + diagonal));
             }
             staged += __popc(m);
             if (staged > kHitStage - 32) staged = flush_hits(sink, staged, lane);
@@ -178,46 +181,75 @@ __device__ __noinline__ uint32_t drain_rows(const HitSink sink, uint32_t staged,
     return staged;
 }
 
-// The expanded model is read through the constant address space: the address
-// is wave-uniform, so hipcc emits s_load_dwordx* into SGPRs (no VGPR, no
-// vmcnt wait in the row loop).  Legal because the kernel never writes it.
-typedef uint32_t row16_t __attribute__((ext_vector_type(2)));   // {A,C} , {G,T} as int16 pairs
-typedef const __attribute__((address_space(4))) row16_t* const_rows_t;
+// The padded model is read through the constant address space: the address is
+// wave-uniform, so hipcc emits s_load_dwordx16 into SGPRs (no VGPR, no vmcnt
+// wait in the row loop).  Legal because the kernel never writes it.
+typedef const __attribute__((address_space(4))) uint32_t* const_rows_t;
 
-// One model row over the lane's 32 diagonals.  R is the row inside the chunk:
-// a template parameter so that every selector index is a compile-time constant
-// and the sliding symbol window costs no instruction.
+__device__ __forceinline__ uint32_t match_pair(uint32_t row, uint32_t selector) {
+    return __builtin_amdgcn_perm(row, row, selector);     // (row[a] << 8) | (row[b] << 24)
+}
+
+// One bit per cell of the lane: set where the cell's low byte is non-zero (it crossed 256).
+// Bit q stands for the lane's diagonal 4*(q & 7) + (q >> 3): the layout that costs least here,
+// two registers per v_perm; drain_rows undoes it.
+__device__ __forceinline__ uint32_t crossed_mask(const uint32_t (&v)[kRegs]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < kRegs / 2; j++) {
+        // bytes: [v[2j] low cell, v[2j] high cell, v[2j+1] low cell, v[2j+1] high cell], each 0xff or 0x00 in bit 0
+        const uint32_t w = __builtin_amdgcn_perm(v[2 * j + 1], v[2 * j], 0x06040200u) & 0x01010101u;
+        m |= w << j;
+    }
+    return m;
+}
+
+// Two model rows (R even, R+1) over the lane's 32 diagonals.  R is a template
+// parameter so that every selector index is a compile-time constant.
 template <int R>
-__device__ __forceinline__ void row_step(uint32_t (&x)[kRegs], const uint32_t (&W)[32], const uint32_t (&Wodd)[31],
-                                         const row16_t row, uint32_t* __restrict__ row_masks, uint32_t& rows_with_hits,
-                                         int lane) {
+__device__ __forceinline__ void row_pair_step(uint32_t (&x)[kRegs], const uint32_t (&W)[32], const uint32_t (&Wodd)[31],
+                                              const uint32_t row0, const uint32_t row1, uint32_t* __restrict__ row_masks,
+                                              uint32_t& rows_with_hits, int lane) {
+    uint32_t y[kRegs];       // scores after row R; x becomes the scores after row R+1
     uint32_t any = 0;
 #pragma unroll
+    for (int i = 0; i < kRegs; i++) y[i] = sat_add_pk16(x[i], match_pair(row0, W[(R >> 1) + i]));
+#pragma unroll
     for (int i = 0; i < kRegs; i++) {
-        const uint32_t sel = (R & 1) ? Wodd[(R >> 1) + i] : W[(R >> 1) + i];
-        const uint32_t m = __builtin_amdgcn_perm(row.y, row.x, sel);
-        x[i] = sat_add_pk16(x[i], m);
+        x[i] = sat_add_pk16(y[i], match_pair(row1, Wodd[(R >> 1) + i]));
         any |= x[i];
     }
-    if (__builtin_expect(__any((any & kHitBits) != 0), 0)) {
-        uint32_t mask = 0;
+    if (__builtin_expect(__any((any & kCrossedBits) != 0), 0)) {
+        const uint32_t mask0 = crossed_mask(y);                       // crossed 256 on row R
+        const uint32_t mask1 = crossed_mask(x) & ~mask0;              // on row R+1 (a row-R mark is still on x)
+        if (__any(mask0 != 0)) {
+            // a cell that crossed on row R restarts from 0 (SoftSsv.cpp:43-44): redo its row R+1 from there
 #pragma unroll
-        for (int i = 0; i < kRegs; i++) {
-            const uint32_t h = (x[i] >> 8) & 0x00010001u;              // bit 0 / bit 16: low / high cell crossed 256
-            mask |= ((h | (h >> 15)) & 3u) << (2 * i);
-            const uint32_t sel16 = h * 0xffffu;                       // 0xffff over each crossed cell
-            x[i] = (x[i] & ~sel16) | (kScoreZero & sel16);             // crossed cells restart at 0 (SoftSsv.cpp:43-44)
+            for (int i = 0; i < kRegs; i++) {
+                const uint32_t s0 = (y[i] & kCrossedBits) * 0xffffu;   // 0xffff over each cell marked on row R
+                const uint32_t sx = (x[i] & kCrossedBits) * 0xffffu;   // ... marked on either row
+                const uint32_t fresh = sat_add_pk16(kScoreZero, match_pair(row1, Wodd[(R >> 1) + i]));
+                const uint32_t repl = (fresh & s0) | (kScoreZero & ~s0);
+                x[i] = (repl & sx) | (x[i] & ~sx);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kRegs; i++) {
+                const uint32_t sx = (x[i] & kCrossedBits) * 0xffffu;
+                x[i] = (kScoreZero & sx) | (x[i] & ~sx);               // crossed cells restart at 0
+            }
         }
-        row_masks[R * 64 + lane] = mask;
-        rows_with_hits |= 1u << R;
+        row_masks[R * 64 + lane] = mask0;
+        row_masks[(R + 1) * 64 + lane] = mask1;
+        rows_with_hits |= 3u << R;
     }
 }
 
-template <int... R>
+template <int... P>
 __device__ __forceinline__ void chunk_rows(uint32_t (&x)[kRegs], const uint32_t (&W)[32], const uint32_t (&Wodd)[31],
-                                           const row16_t (&row)[kChunkRows], uint32_t* __restrict__ row_masks,
-                                           uint32_t& rows_with_hits, int lane, std::integer_sequence<int, R...>) {
-    (row_step<R>(x, W, Wodd, row[R], row_masks, rows_with_hits, lane), ...);
+                                           const uint32_t (&row)[kChunkRows], uint32_t* __restrict__ row_masks,
+                                           uint32_t& rows_with_hits, int lane, std::integer_sequence<int, P...>) {
+    (row_pair_step<2 * P>(x, W, Wodd, row[2 * P], row[2 * P + 1], row_masks, rows_with_hits, lane), ...);
 }
 
 // Selector words of the 4 symbols of one packed byte, through a 256-entry LDS
@@ -228,8 +260,8 @@ __device__ __forceinline__ uint2 byte_selectors(const uint2* __restrict__ lut, u
     return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(lut) + off);
 }
 
-__global__ __launch_bounds__(64 * kWavesPerBlock)
-void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, const uint2* __restrict__ rows16,
+__global__ __launch_bounds__(64 * kWavesPerBlock, 4)   // 4 waves per SIMD: at most 128 VGPRs
+void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, const uint32_t* __restrict__ rows8,
                      const uint32_t nrows_padded, const int64_t first_diag, const uint32_t tile_begin,
                      const uint32_t tile_end, uint64_t* __restrict__ hits, unsigned long long* __restrict__ hit_count,
                      const uint64_t hit_capacity, const uint32_t* __restrict__ abort_flag) {
@@ -279,7 +311,7 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
             W[base + 8 + 2 * b] = s1.x; W[base + 8 + 2 * b + 1] = s1.y;
         }
         if (edge) {
-            // positions outside [0, N) score -256: pins the cell at 0, never hits
+            // positions outside [0, N) score -1: pins the cell at 0, never hits
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const int64_t q = pos + 2 * k;     // q and q+1 are in or out together (pos, N even)
@@ -295,8 +327,8 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
         if (abort_flag && ((p0 & 2047) == 0) && p0 != p_lo &&
             __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
         // rows of the chunk: fetched in two batches of scalar loads, the second lands while rows 0..15 run
-        const const_rows_t rows = (const_rows_t)(const row16_t*)(rows16 + p0);
-        row16_t row[kChunkRows];
+        const const_rows_t rows = (const_rows_t)(rows8 + p0);
+        uint32_t row[kChunkRows];
 #pragma unroll
         for (int r = 0; r < kChunkRows / 2; r++) row[r] = rows[r];
 
@@ -319,7 +351,7 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
         for (int r = kChunkRows / 2; r < kChunkRows; r++) row[r] = rows[r];
 
         uint32_t rows_with_hits = 0;   // wave-uniform
-        chunk_rows(x, W, Wodd, row, sink.row_masks, rows_with_hits, lane, std::make_integer_sequence<int, kChunkRows>{});
+        chunk_rows(x, W, Wodd, row, sink.row_masks, rows_with_hits, lane, std::make_integer_sequence<int, kChunkRows / 2>{});
         if (rows_with_hits) staged = drain_rows(sink, staged, rows_with_hits, (uint32_t)p0, d0 + p0, lane);
     }
     flush_hits(sink, staged, lane);
