@@ -209,19 +209,20 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     HIP_TRY(c->err, hipSetDevice(c->device));
 
     Tiling t = make_tiling(nsymbols, nrows);
-    if (c->rows8_rows < t.nrows_padded) {
+    const uint32_t model_words = t.nrows_padded + kModelSlack;   // "row -1", the rows, padding rows
+    if (c->rows8_rows < model_words) {
         if (c->rows8) (void)hipFree(c->rows8);
         c->rows8 = nullptr; c->rows8_rows = 0;
-        HIP_TRY(c->err, hipMalloc(&c->rows8, (size_t)t.nrows_padded * sizeof(uint32_t)));
-        c->rows8_rows = t.nrows_padded;
+        HIP_TRY(c->err, hipMalloc(&c->rows8, (size_t)model_words * sizeof(uint32_t)));
+        c->rows8_rows = model_words;
     }
     uint32_t tb, te;
     shard_tiles(t, nsymbols, shard_index, shard_count, &tb, &te);
 
     HIP_TRY(c->err, hipEventRecord(c->ev[0], stream));
     HIP_TRY(c->err, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), stream));
-    hipLaunchKernelGGL(ssv_pad_model, dim3((t.nrows_padded + 255) / 256), dim3(256), 0, stream,
-                       d_phmm, nrows, c->rows8, t.nrows_padded);
+    hipLaunchKernelGGL(ssv_pad_model, dim3((model_words + 255) / 256), dim3(256), 0, stream,
+                       d_phmm, nrows, c->rows8, model_words);
     HIP_TRY(c->err, hipEventRecord(c->ev[1], stream));
     if (te > tb) {
         uint32_t nblocks = (te - tb + kWavesPerBlock - 1) / kWavesPerBlock;

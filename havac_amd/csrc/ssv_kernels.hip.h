@@ -18,25 +18,32 @@
 //    score 0, and saturation at +32767 IS the threshold: score + match >= 256
 //    exactly when the sum leaves the int16 range.  Every regular value is a
 //    multiple of 256, so a crossed cell is recognisable afterwards by a non-zero
-//    low byte (0x7fff), and it stays recognisable for at least one more row
+//    low byte (0x7fff), and it stays recognisable for at least one more step
 //    (0x7fff + 256*m keeps the low byte unless it saturates again at the top).
-//    That is why hits are looked for only once per PAIR of rows.
-//  * MATCH SCORES BY v_perm_b32 straight from the reference's int8 row word: the
-//    selector of a diagonal pair with symbols (a,b) is the byte pattern
-//    [0x0c, a, 0x0c, b] (0x0c selects the constant 0x00), which yields
-//    (M[a] << 8) | (M[b] << 24): both match scores, already multiplied by 256.
-//    The 2-bit symbols are expanded into selectors once per 32-row chunk through
-//    an LDS table.  The symbol window slides one position per row; even rows use
-//    the aligned selector words, odd rows the words shifted by 16 bits, both
-//    indexed statically in the fully unrolled chunk, so the slide costs nothing.
-//  * OUTSIDE THE MATRIX (columns < 0 or >= N, rows >= nrows) the selector
-//    / row yields a negative score, which pins the cell at 0 and can never hit:
-//    no per-cell predicate anywhere in the hot loop.
-//  * HITS are rare (about 1e-5 per cell on Dfam-like models): after each row pair
-//    the 16 score registers are OR-ed and one wave-wide test looks at the low
-//    bytes; only then the slow path sorts out which row crossed, repairs the
-//    second row for cells that crossed on the first (they restart from 0,
-//    test/softSsv/SoftSsv.cpp:43-44), and parks one mask per row in LDS.
+//    That is why hits are looked for only once per PAIR of steps.
+//  * SKEWED PAIRS.  The two cells of a register sit on adjacent diagonals, and
+//    the high cell runs ONE ROW BEHIND the low cell: at step t the low cell is
+//    (row t, diagonal e) and the high cell (row t-1, diagonal e+1) -- the same
+//    column, hence the same sequence symbol.  The match word of a register at
+//    step t therefore depends on ONE symbol: (M[t][a] << 8) | (M[t-1][a] << 24).
+//  * MATCH WORDS COME FROM LDS, NOT FROM THE VALU.  Two consecutive steps of a
+//    register use two consecutive symbols (a, b), so a 16-entry x 8-byte table
+//    per step pair, indexed by the 4-bit code of the symbol pair, returns both
+//    steps' match words in one conflict-free ds_read_b64 (16 entries x 2 banks
+//    = 32 distinct banks).  The wave rebuilds its 16 tables (2.2 KB) once per
+//    32-step chunk with 8 v_perm_b32 per lane.  A 17th entry per table scores
+//    -1 for "outside the matrix" (columns < 0 or >= N), which pins a cell at 0
+//    and can never hit: the hot loop has no per-cell predicate and no separate
+//    edge path.  What remains on the VALU per register and step pair is two
+//    v_pk_add_i16 and half a v_or3_b32.
+//  * The symbol window slides one position per step; the 32 step-pair codes a
+//    lane needs per chunk are addresses (code*8 + table base) held in VGPRs and
+//    indexed statically in the fully unrolled chunk, so the slide is free.
+//  * HITS are rare (about 1e-5 per cell on Dfam-like models): after each step
+//    pair the 16 score registers are OR-ed and one wave-wide test looks at the
+//    low bytes; only then the slow path sorts out which step crossed, repairs
+//    the second step for cells that crossed on the first (they restart from 0,
+//    test/softSsv/SoftSsv.cpp:43-44), and parks one mask per step in LDS.
 //    Records leave through LDS staging with one atomic per burst and are put in
 //    the FPGA's order afterwards.
 //
@@ -52,12 +59,21 @@ namespace havac {
 constexpr int kDiagsPerLane = 32;                 // 16 VGPRs x 2 int16
 constexpr int kRegs = kDiagsPerLane / 2;
 constexpr int kTileDiags = 64 * kDiagsPerLane;    // one wave
-constexpr int kChunkRows = 32;                    // rows per unrolled chunk
+constexpr int kChunkRows = 32;                    // steps per unrolled chunk
+constexpr int kChunkPairs = kChunkRows / 2;
 constexpr int kWavesPerBlock = 4;
+constexpr int kModelSlack = 40;                   // padding rows kept behind the padded model (table look-ahead)
 constexpr uint32_t kScoreZero = 0x80008000u;      // two cells at score 0: 256*0 - 32768
 constexpr uint32_t kCrossedBits = 0x00010001u;    // bit 0 of either cell: set only in 0x7fff-derived values
-constexpr uint32_t kPadSelector = 0x0d0c0d0cu;    // v_perm: bytes (0x00,0xff) -> 0xff00 = score -1, twice
-constexpr uint32_t kPadRow = 0x80808080u;         // a row past the model: -128 for every symbol
+constexpr uint32_t kOutsideWord = 0xff00ff00u;    // match word "score -1" for both cells
+constexpr uint32_t kPadRow = 0x80808080u;         // a row outside the model: -128 for every symbol
+
+// per-wave LDS: 16 step-pair tables of 17 entries x 8 B, the parked hit masks of half a chunk, the record stage
+constexpr int kPairStride = 17 * 8;               // 16 symbol-pair codes + the "outside the matrix" entry
+constexpr uint32_t kOutsideCode = 16 * 8;         // byte offset of that entry
+constexpr int kTableBytes = 2304;                 // 16 x 136 = 2176, rounded up to a multiple of 128
+constexpr int kHitStage = 128;                    // records staged per wave (1 KiB)
+constexpr int kMaskSteps = kChunkRows / 2;        // masks are drained twice per chunk
 
 // sort key of a hit: (segment, row, column-in-segment) -- the FPGA's emission
 // order (device/HavacHls.cpp:151-152,264; device/HitReporting.cpp:178-337)
@@ -82,31 +98,26 @@ __device__ __forceinline__ uint64_t record_to_key(uint64_t rec) {
 }
 
 // ---------------------------------------------------------------------------
-// model int8 [row][A,C,G,T] -> the same words, padded with rows of -128 up to a
-// whole number of chunks (a padding row can only lower a score).  The kernel
-// reads the copy through the constant address space.
+// model int8 [row][A,C,G,T] -> the same words shifted by one: out[0] is "row -1"
+// (all -128), out[1 + r] is row r, and everything from row nrows on is -128
+// again (a padding row can only lower a score).  nrows_padded + kModelSlack words.
 __global__ void ssv_pad_model(const int8_t* __restrict__ phmm, uint32_t nrows,
-                              uint32_t* __restrict__ rows8, uint32_t nrows_padded) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows_padded) return;
-    rows8[r] = r < nrows ? reinterpret_cast<const uint32_t*>(phmm)[r] : kPadRow;
+                              uint32_t* __restrict__ rows, uint32_t nwords) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwords) return;
+    rows[i] = (i >= 1 && i <= nrows) ? reinterpret_cast<const uint32_t*>(phmm)[i - 1] : kPadRow;
 }
 
 // ---------------------------------------------------------------------------
 typedef short short2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) u32x2* lds_words_t;
+typedef __attribute__((address_space(3))) u32x2* lds_words_out_t;
 
 __device__ __forceinline__ uint32_t sat_add_pk16(uint32_t a, uint32_t b) {
     short2v r = __builtin_elementwise_add_sat(__builtin_bit_cast(short2v, a),
                                               __builtin_bit_cast(short2v, b));
     return __builtin_bit_cast(uint32_t, r);
-}
-
-// selector word for the two symbols in bits [shift+3 : shift] of w: bytes
-// [0x0c, a, 0x0c, b] (a = low symbol) -> v_perm gives (row[a] << 8) | (row[b] << 24)
-__device__ __forceinline__ uint32_t pair_selector(uint32_t w, int shift) {
-    uint32_t a = (w >> shift) & 3u;
-    uint32_t b = (w >> (shift + 2)) & 3u;
-    return 0x000c000cu | (a << 8) | (b << 24);
 }
 
 // 8 bytes = 32 symbols at symbol offset `pos` (multiple of 32); zero outside the buffer
@@ -116,25 +127,26 @@ __device__ __forceinline__ uint2 load_symbols(const uint8_t* __restrict__ seq, i
     return *reinterpret_cast<const uint2*>(seq + (pos >> 2));
 }
 
+// ---- per-wave LDS ------------------------------------------------------------
+struct __attribute__((aligned(128))) WaveLds {
+    uint8_t table[kTableBytes];            // match words of the current chunk
+    uint32_t masks[kMaskSteps * 64];       // parked hit masks, [step in half chunk][lane]
+    uint64_t stage[kHitStage];             // records waiting for the next burst
+};
+
 // ---- hit queue --------------------------------------------------------------
 // Counterpart of the FPGA's five-stage hit sieve (device/HitReporting.cpp:12-417).
-// Hot loop: the 16 score registers of a row are OR-ed and one wave-wide test
-// looks for bit 8.  Only a wave that sees it runs the per-row slow path, which
-// turns the crossings into one 32-bit mask per lane (bit b = diagonal b of the
-// lane), resets those cells to 0 and parks the mask in LDS.  Once per 32-row
-// chunk the parked masks are turned into records, staged in the wave's LDS
-// slice and appended to the global queue in bursts: one returning atomic per
-// burst instead of one per hit (a single counter word sustains only ~90
-// returning atomics per microsecond chip-wide, which capped the first version
-// of this kernel at ~90 M hits/s).
-constexpr int kHitStage = 128;                    // records staged per wave (1 KiB of LDS)
-
+// A wave that sees a crossing parks one 32-bit mask per lane and step in LDS.
+// Twice per chunk the parked masks are turned into records, staged in LDS and
+// appended to the global queue in bursts: one returning atomic per burst
+// instead of one per hit (a single counter word sustains only ~90 returning
+// atomics per microsecond chip-wide, which capped the first version of this
+// kernel at ~90 M hits/s).
 struct HitSink {
     uint64_t* hits;                // global queue of sort keys (hit_key)
     unsigned long long* hit_count; // records found so far (may run past capacity)
     uint64_t hit_capacity;
-    uint64_t* stage;               // this wave's LDS slice, kHitStage records
-    uint32_t* row_masks;           // this wave's LDS slice, kChunkRows x 64 masks
+    WaveLds* lds;
 };
 
 __device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t staged, int lane) {
@@ -147,23 +159,25 @@ __device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t sta
     base = ((unsigned long long)hi << 32) | lo;
     for (uint32_t i = lane; i < staged; i += 64) {
         const unsigned long long idx = base + i;
-        if (idx < sink.hit_capacity) sink.hits[idx] = sink.stage[i];
+        if (idx < sink.hit_capacity) sink.hits[idx] = sink.lds->stage[i];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     return 0;
 }
 
-// Once per chunk, only if some row of the chunk parked masks.  `rows_with_hits`
-// has bit r set for row p0 + r.  Bit q of lane l's mask is the lane's diagonal
-// 4*(q & 7) + (q >> 3) (see crossed_mask), whose column on row p0 + r is
-// wave_column0 + r + 32*l + that.  Returns the new number of staged records.
-__device__ __noinline__ uint32_t drain_rows(const HitSink sink, uint32_t staged, uint32_t rows_with_hits, uint32_t p0,
-                                            int64_t wave_column0, int lane) {
+// Twice per chunk, only if some step of the half chunk parked masks.
+// `steps_with_hits` has bit r set for step step0 + r.  Bit q of a lane's mask
+// stands for register 2*(q & 7) + (q >> 4), cell (q >> 3) & 1 (see crossed_mask).
+// At step t the low cell of register g of lane l is (row t, column c) and the
+// high cell (row t - 1, column c), with c = wave_diag0 + 32*l + 2*g + t.
+__device__ __noinline__ uint32_t drain_steps(const HitSink sink, uint32_t staged, uint32_t steps_with_hits,
+                                             uint32_t step0, int64_t wave_diag0, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    while (rows_with_hits) {
-        const int r = __builtin_ctz(rows_with_hits);
-        rows_with_hits &= rows_with_hits - 1;
-        const uint32_t mask = sink.row_masks[r * 64 + lane];
+    while (steps_with_hits) {
+        const int r = __builtin_ctz(steps_with_hits);
+        steps_with_hits &= steps_with_hits - 1;
+        const uint32_t t = step0 + r;
+        const uint32_t mask = sink.lds->masks[r * 64 + lane];
         unsigned long long lanes = __ballot(mask != 0);
         while (lanes) {
             const int src = __builtin_ctzll(lanes);
@@ -171,8 +185,9 @@ __device__ __noinline__ uint32_t drain_rows(const HitSink sink, uint32_t staged,
             const uint32_t m = __builtin_amdgcn_readlane(mask, src);
             if (lane < 32 && ((m >> lane) & 1u)) {
                 const uint32_t pos = staged + __popc(m & ((1u << lane) - 1u));
-                const int diagonal = 4 * (lane & 7) + (lane >> 3);
-                sink.stage[pos] = hit_key(p0 + r, (uint64_t)(wave_column0 + r + 32 * src + diagonal));
+                const int reg = 2 * (lane & 7) + (lane >> 4);
+                const int high = (lane >> 3) & 1;
+                sink.lds->stage[pos] = hit_key(t - high, (uint64_t)(wave_diag0 + 32 * src + 2 * reg + (int64_t)t));
             }
             staged += __popc(m);
             if (staged > kHitStage - 32) staged = flush_hits(sink, staged, lane);
@@ -181,178 +196,196 @@ __device__ __noinline__ uint32_t drain_rows(const HitSink sink, uint32_t staged,
     return staged;
 }
 
-// The padded model is read through the constant address space: the address is
-// wave-uniform, so hipcc emits s_load_dwordx16 into SGPRs (no VGPR, no vmcnt
-// wait in the row loop).  Legal because the kernel never writes it.
-typedef const __attribute__((address_space(4))) uint32_t* const_rows_t;
-
-__device__ __forceinline__ uint32_t match_pair(uint32_t row, uint32_t selector) {
-    return __builtin_amdgcn_perm(row, row, selector);     // (row[a] << 8) | (row[b] << 24)
-}
-
 // One bit per cell of the lane: set where the cell's low byte is non-zero (it crossed 256).
-// Bit q stands for the lane's diagonal 4*(q & 7) + (q >> 3): the layout that costs least here,
-// two registers per v_perm; drain_rows undoes it.
+// Bit q = 8*b + j stands for register 2j + (b >> 1), cell b & 1: the layout that costs least
+// here, two registers per v_perm; drain_steps undoes it.
 __device__ __forceinline__ uint32_t crossed_mask(const uint32_t (&v)[kRegs]) {
     uint32_t m = 0;
 #pragma unroll
     for (int j = 0; j < kRegs / 2; j++) {
-        // bytes: [v[2j] low cell, v[2j] high cell, v[2j+1] low cell, v[2j+1] high cell], each 0xff or 0x00 in bit 0
+        // bytes: [v[2j] low cell, v[2j] high cell, v[2j+1] low cell, v[2j+1] high cell], bit 0 = crossed
         const uint32_t w = __builtin_amdgcn_perm(v[2 * j + 1], v[2 * j], 0x06040200u) & 0x01010101u;
         m |= w << j;
     }
     return m;
 }
 
-// Two model rows (R even, R+1) over the lane's 32 diagonals.  R is a template
-// parameter so that every selector index is a compile-time constant.
-template <int R>
-__device__ __forceinline__ void row_pair_step(uint32_t (&x)[kRegs], const uint32_t (&W)[32], const uint32_t (&Wodd)[31],
-                                              const uint32_t row0, const uint32_t row1, uint32_t* __restrict__ row_masks,
-                                              uint32_t& rows_with_hits, int lane) {
-    uint32_t y[kRegs];       // scores after row R; x becomes the scores after row R+1
+// both steps' match words of one register: one ds_read_b64, table of step pair P, entry `code_addr`
+template <int P>
+__device__ __forceinline__ u32x2 match_words(uint32_t code_addr) {
+    return *(lds_words_t)(uintptr_t)(code_addr + P * kPairStride);
+}
+
+// Steps 2P and 2P+1 of the chunk over the lane's 32 diagonals.  P is a template parameter so that
+// every window index and LDS offset is a compile-time constant.
+//
+// The scores ping-pong between two register sets: on entry `cur` holds the scores, the first step
+// updates `cur` in place (it then holds the scores after step 2P, which the slow path needs), the
+// second step writes `nxt`; the next pair is instantiated with the sets swapped.  Both adds are
+// written as read-modify-write asm so that every score keeps its VGPR through the whole unrolled
+// chunk (left to itself hipcc re-homes the 16 registers with v_mov after every pair).
+template <int P>
+__device__ __forceinline__ void step_pair(uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
+                                          uint32_t* __restrict__ masks, uint32_t& steps_with_hits, int lane) {
     uint32_t any = 0;
+    u32x2 m[kRegs];
 #pragma unroll
-    for (int i = 0; i < kRegs; i++) y[i] = sat_add_pk16(x[i], match_pair(row0, W[(R >> 1) + i]));
+    for (int i = 0; i < kRegs; i++) m[i] = match_words<P>(C[P + i]);
+#pragma unroll
+    for (int i = 0; i < kRegs; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(cur[i]) : "v"(m[i].x));
 #pragma unroll
     for (int i = 0; i < kRegs; i++) {
-        x[i] = sat_add_pk16(y[i], match_pair(row1, Wodd[(R >> 1) + i]));
-        any |= x[i];
+        asm("v_pk_add_i16 %0, %1, %2 clamp" : "+v"(nxt[i]) : "v"(cur[i]), "v"(m[i].y));
+        any |= nxt[i];
     }
     if (__builtin_expect(__any((any & kCrossedBits) != 0), 0)) {
-        const uint32_t mask0 = crossed_mask(y);                       // crossed 256 on row R
-        const uint32_t mask1 = crossed_mask(x) & ~mask0;              // on row R+1 (a row-R mark is still on x)
+        const uint32_t mask0 = crossed_mask(cur);                     // crossed 256 on the first step
+        const uint32_t mask1 = crossed_mask(nxt) & ~mask0;            // on the second (a first-step mark is still on nxt)
         if (__any(mask0 != 0)) {
-            // a cell that crossed on row R restarts from 0 (SoftSsv.cpp:43-44): redo its row R+1 from there
+            // a cell that crossed on the first step restarts from 0 (SoftSsv.cpp:43-44): redo its second step
 #pragma unroll
             for (int i = 0; i < kRegs; i++) {
-                const uint32_t s0 = (y[i] & kCrossedBits) * 0xffffu;   // 0xffff over each cell marked on row R
-                const uint32_t sx = (x[i] & kCrossedBits) * 0xffffu;   // ... marked on either row
-                const uint32_t fresh = sat_add_pk16(kScoreZero, match_pair(row1, Wodd[(R >> 1) + i]));
+                const uint32_t s0 = (cur[i] & kCrossedBits) * 0xffffu;  // 0xffff over each cell marked on the first step
+                const uint32_t sx = (nxt[i] & kCrossedBits) * 0xffffu;  // ... marked on either step
+                const uint32_t fresh = sat_add_pk16(kScoreZero, match_words<P>(C[P + i]).y);
                 const uint32_t repl = (fresh & s0) | (kScoreZero & ~s0);
-                x[i] = (repl & sx) | (x[i] & ~sx);
+                nxt[i] = (repl & sx) | (nxt[i] & ~sx);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < kRegs; i++) {
-                const uint32_t sx = (x[i] & kCrossedBits) * 0xffffu;
-                x[i] = (kScoreZero & sx) | (x[i] & ~sx);               // crossed cells restart at 0
+                const uint32_t sx = (nxt[i] & kCrossedBits) * 0xffffu;
+                nxt[i] = (kScoreZero & sx) | (nxt[i] & ~sx);            // crossed cells restart at 0
             }
         }
-        row_masks[R * 64 + lane] = mask0;
-        row_masks[(R + 1) * 64 + lane] = mask1;
-        rows_with_hits |= 3u << R;
+        constexpr int r = (2 * P) % kMaskSteps;
+        masks[r * 64 + lane] = mask0;
+        masks[(r + 1) * 64 + lane] = mask1;
+        steps_with_hits |= 3u << r;
     }
 }
 
-template <int... P>
-__device__ __forceinline__ void chunk_rows(uint32_t (&x)[kRegs], const uint32_t (&W)[32], const uint32_t (&Wodd)[31],
-                                           const uint32_t (&row)[kChunkRows], uint32_t* __restrict__ row_masks,
-                                           uint32_t& rows_with_hits, int lane, std::integer_sequence<int, P...>) {
-    (row_pair_step<2 * P>(x, W, Wodd, row[2 * P], row[2 * P + 1], row_masks, rows_with_hits, lane), ...);
+// pairs First .. First+N-1; the scores are in `a` on entry and, N being even, in `a` again on exit
+template <int First, int... I>
+__device__ __forceinline__ void step_pairs(uint32_t (&a)[kRegs], uint32_t (&b)[kRegs], const uint32_t (&C)[32],
+                                           uint32_t* __restrict__ masks, uint32_t& steps_with_hits, int lane,
+                                           std::integer_sequence<int, I...>) {
+    static_assert(sizeof...(I) % 2 == 0, "an even number of pairs returns the scores to the first set");
+    ((I % 2 == 0 ? step_pair<First + I>(a, b, C, masks, steps_with_hits, lane)
+                 : step_pair<First + I>(b, a, C, masks, steps_with_hits, lane)), ...);
 }
 
-// Selector words of the 4 symbols of one packed byte, through a 256-entry LDS
-// table (2 KiB per workgroup, built once): two words per ds_read_b64 instead
-// of ten VALU instructions.
-__device__ __forceinline__ uint2 byte_selectors(const uint2* __restrict__ lut, uint32_t w, int byte) {
-    const uint32_t off = (byte == 0 ? (w << 3) : (w >> (8 * byte - 3))) & 0x7f8u;   // byte value * 8
-    return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(lut) + off);
-}
+// selector of the match word of symbol a: bytes [0x0c, a, 0x0c, 4 + a]; with v_perm(S0 = row t-1, S1 = row t) it
+// yields (row_t[a] << 8) | (row_tm1[a] << 24)
+__device__ __forceinline__ uint32_t word_selector(uint32_t a) { return 0x040c000cu + a * 0x01000100u; }
 
 __global__ __launch_bounds__(64 * kWavesPerBlock, 4)   // 4 waves per SIMD: at most 128 VGPRs
-void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, const uint32_t* __restrict__ rows8,
+void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, const uint32_t* __restrict__ rows,
                      const uint32_t nrows_padded, const int64_t first_diag, const uint32_t tile_begin,
                      const uint32_t tile_end, uint64_t* __restrict__ hits, unsigned long long* __restrict__ hit_count,
                      const uint64_t hit_capacity, const uint32_t* __restrict__ abort_flag) {
-    __shared__ uint64_t hit_stage[kWavesPerBlock][kHitStage];
-    __shared__ uint32_t hit_masks[kWavesPerBlock][kChunkRows * 64];
-    __shared__ uint2 selector_lut[256];
-
-    // table entry b: selectors of symbol pairs (s0,s1) and (s2,s3) of packed byte b
-    selector_lut[threadIdx.x] = make_uint2(pair_selector(threadIdx.x, 0), pair_selector(threadIdx.x, 4));
-    __syncthreads();
+    __shared__ WaveLds wave_lds[kWavesPerBlock];
 
     const int lane = threadIdx.x & 63;
-    // readfirstlane: everything derived from the tile index is wave-uniform, which lets hipcc keep
-    // the row pointer in SGPRs (scalar loads of the model rows) and branch on `edge` with SALU
+    // readfirstlane: everything derived from the tile index is wave-uniform (SALU branches, scalar address math)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t tile = tile_begin + blockIdx.x * kWavesPerBlock + wave;
     if (tile >= tile_end) return;
-    const HitSink sink{hits, hit_count, hit_capacity, hit_stage[wave], hit_masks[wave]};
+    WaveLds* const lds = &wave_lds[wave];
+    const HitSink sink{hits, hit_count, hit_capacity, lds};
     uint32_t staged = 0;          // wave-uniform
 
     const int64_t d0 = first_diag + (int64_t)tile * kTileDiags;     // wave's first diagonal
     const int64_t dl = d0 + lane * kDiagsPerLane;                   // lane's first diagonal
-    // rows whose cells of this tile can lie inside the matrix
+    // steps whose cells of this tile can lie inside the matrix
     int64_t p_lo = -d0 - kTileDiags;                                // first chunk touching column >= 0
     if (p_lo < 0) p_lo = 0;
     int64_t p_hi = nsymbols - d0;                                   // first chunk entirely at columns >= N
     if (p_hi > (int64_t)nrows_padded) p_hi = nrows_padded;
     if (p_lo >= p_hi) return;
 
-    uint32_t x[kRegs];
+    // LDS byte address of this wave's tables (a multiple of 128: code*8 is OR-ed into it)
+    const uint32_t table_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds->table;
+    // this lane's share of the table build: symbol-pair code `entry` of step pairs pair_group, +4, +8, +12
+    const uint32_t entry = lane & 15, pair_group = lane >> 4;
+    const uint32_t sel_first = word_selector(entry & 3u), sel_second = word_selector(entry >> 2);
+    const uint32_t my_entry_addr = table_base + pair_group * kPairStride + entry * 8;
+    if (entry == 0) {     // the "outside the matrix" entries never change
 #pragma unroll
-    for (int i = 0; i < kRegs; i++) x[i] = kScoreZero;
+        for (int m = 0; m < 4; m++)
+            *(lds_words_out_t)(uintptr_t)(table_base + (pair_group + 4 * m) * kPairStride + kOutsideCode) =
+                u32x2{kOutsideWord, kOutsideWord};
+    }
 
-    // Selector window of the current chunk, symbol positions [j, j+64) with j = dl + p0:
-    // W[k] serves symbols (j+2k, j+2k+1), Wodd[k] symbols (j+2k+1, j+2k+2).  The upper half of one
-    // chunk's window is the lower half of the next, so each chunk expands only 32 new symbols.
-    uint32_t W[32], Wodd[31];
-    auto expand = [&](int64_t rel, int base) {     // symbols [dl+rel, dl+rel+32) -> W[base .. base+16); rel is wave-uniform
+    uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_pair)
+#pragma unroll
+    for (int i = 0; i < kRegs; i++) x[i] = x2[i] = kScoreZero;
+
+    // Window of the current chunk, symbol positions [j, j+64) with j = dl + p0: C[k] is the LDS address of the
+    // table entry of the symbol pair (j+2k, j+2k+1).  The upper half of one chunk's window is the lower half of the
+    // next, so each chunk expands only the 32 new symbols.
+    uint32_t C[32];
+    auto expand = [&](int64_t rel) {     // symbols [dl+rel, dl+rel+32) -> C[16 .. 32); rel is wave-uniform
         const bool edge = (d0 + rel < 0) || (d0 + rel + kTileDiags > nsymbols);   // the wave's 2048 positions
         const int64_t pos = dl + rel;
         const uint2 packed = load_symbols(seq, nsymbols, pos, edge);
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const uint2 s0 = byte_selectors(selector_lut, packed.x, b);
-            const uint2 s1 = byte_selectors(selector_lut, packed.y, b);
-            W[base + 2 * b] = s0.x;     W[base + 2 * b + 1] = s0.y;
-            W[base + 8 + 2 * b] = s1.x; W[base + 8 + 2 * b + 1] = s1.y;
+        for (int k = 0; k < 16; k++) {
+            const uint32_t w = k < 8 ? packed.x : packed.y;
+            const int sh = (k & 7) * 4;                                  // the pair's 4 bits start here
+            const uint32_t code8 = sh == 0 ? (w << 3) : (w >> (sh - 3)); // code * 8 in bits [6:3]
+            C[16 + k] = (code8 & 0x78u) | table_base;
         }
         if (edge) {
-            // positions outside [0, N) score -1: pins the cell at 0, never hits
+            // positions outside [0, N) use the entry that scores -1: pins the cell at 0, never hits
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const int64_t q = pos + 2 * k;     // q and q+1 are in or out together (pos, N even)
-                if (q < 0 || q >= nsymbols) W[base + k] = kPadSelector;
+                if (q < 0 || q >= nsymbols) C[16 + k] = table_base + kOutsideCode;
             }
         }
     };
-    expand(p_lo, 16);
+    // the chunk's 16 step-pair tables: entry (a,b) of pair P = { word(step 2P, a), word(step 2P+1, b) } with
+    // word(t, a) = (M[t][a] << 8) | (M[t-1][a] << 24); rows[] is shifted by one, so rows[t] is M[t-1]
+    auto build_tables = [&](int64_t p0) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const uint32_t* r = rows + p0 + 2 * (pair_group + 4 * m);
+            const uint32_t r0 = r[0], r1 = r[1], r2 = r[2];
+            u32x2 e;
+            e.x = __builtin_amdgcn_perm(r0, r1, sel_first);
+            e.y = __builtin_amdgcn_perm(r1, r2, sel_second);
+            *(lds_words_out_t)(uintptr_t)(my_entry_addr + 4 * m * kPairStride) = e;
+        }
+    };
+    expand(p_lo);
 
     for (int64_t p0 = p_lo; p0 < p_hi; p0 += kChunkRows) {
         // abort: a device word, read past the caches every 2048 rows (never on a wave's first chunk, so
         // short models pay nothing)
         if (abort_flag && ((p0 & 2047) == 0) && p0 != p_lo &&
             __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
-        // rows of the chunk: fetched in two batches of scalar loads, the second lands while rows 0..15 run
-        const const_rows_t rows = (const_rows_t)(rows8 + p0);
-        uint32_t row[kChunkRows];
-#pragma unroll
-        for (int r = 0; r < kChunkRows / 2; r++) row[r] = rows[r];
-
+        build_tables(p0);
         // slide the window by 32 symbols
 #pragma unroll
-        for (int k = 0; k < 16; k++) W[k] = W[k + 16];
-#pragma unroll
-        for (int k = 0; k < 15; k++) Wodd[k] = Wodd[k + 16];
-        expand(p0 + 32, 16);
-        if (p0 == p_lo) {
-#pragma unroll
-            for (int k = 0; k < 15; k++) Wodd[k] = __builtin_amdgcn_alignbit(W[k + 1], W[k], 16);
-        }
-#pragma unroll
-        for (int k = 15; k < 31; k++) Wodd[k] = __builtin_amdgcn_alignbit(W[k + 1], W[k], 16);
-#pragma unroll
-        for (int k = 0; k < 31; k++) asm volatile("" : "+v"(Wodd[k]));   // keep in VGPRs: hipcc otherwise
-                                                                          // recomputes them in every odd row
-#pragma unroll
-        for (int r = kChunkRows / 2; r < kChunkRows; r++) row[r] = rows[r];
+        for (int k = 0; k < 16; k++) C[k] = C[k + 16];
+        expand(p0 + 32);
 
-        uint32_t rows_with_hits = 0;   // wave-uniform
-        chunk_rows(x, W, Wodd, row, sink.row_masks, rows_with_hits, lane, std::make_integer_sequence<int, kChunkRows / 2>{});
-        if (rows_with_hits) staged = drain_rows(sink, staged, rows_with_hits, (uint32_t)p0, d0 + p0, lane);
+        uint32_t steps_with_hits = 0;   // wave-uniform
+        step_pairs<0>(x, x2, C, lds->masks, steps_with_hits, lane, std::make_integer_sequence<int, kChunkPairs / 2>{});
+        if (steps_with_hits) staged = drain_steps(sink, staged, steps_with_hits, (uint32_t)p0, d0, lane);
+        steps_with_hits = 0;
+        step_pairs<kChunkPairs / 2>(x, x2, C, lds->masks, steps_with_hits, lane, std::make_integer_sequence<int, kChunkPairs / 2>{});
+        if (steps_with_hits) staged = drain_steps(sink, staged, steps_with_hits, (uint32_t)p0 + kMaskSteps, d0, lane);
+    }
+    if (p_hi == (int64_t)nrows_padded) {
+        // the high cells run one row behind: one more step gives them the model's last row
+        build_tables(p_hi);
+#pragma unroll
+        for (int k = 0; k < 16; k++) C[k] = C[k + 16];
+        uint32_t steps_with_hits = 0;
+        step_pair<0>(x, x2, C, lds->masks, steps_with_hits, lane);
+        if (steps_with_hits) staged = drain_steps(sink, staged, steps_with_hits, (uint32_t)p_hi, d0, lane);
     }
     flush_hits(sink, staged, lane);
 }
