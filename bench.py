@@ -42,21 +42,26 @@ COLUMNS_PER_GPU = 100_012_032          # 100 Mbp padded to 12288 (8139 segments)
 ROWS = 1024
 FPGA_GCUPS = 1739.0                    # reference README.md:4 (Alveo U50), BASELINE.md section 1
 
-# Integer-VALU roofline.  The two instructions the recurrence needs -- the byte select v_perm_b32 and
-# the packed saturating add v_pk_add_i16 -- belong to gfx950's HALF-rate VALU class: a wave64
-# instruction holds its SIMD for 4 cycles (16 lanes/clk), measured with tools/valu_rates.hip
-# (profiles/r01_valu_rates_4waves_per_simd.txt; the full-rate class, 2 cycles, is v_add_u32 / v_and /
-# v_fma_f32 ... and has no byte permute or packed saturating add).  Peak for this class:
-# 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3e12 lane-ops/s (the figure SURVEY.md 8d uses),
-# x 2 int16 operations per packed lane-op = 78.6e12 int16 ops/s.
+# Roofline of ssv_diag_kernel.  Not HBM, not MFMA: the kernel is bound by
+# VALU issue.  Per DP cell the recurrence needs one 4:1 score select and one saturating add.  The select is served
+# by LDS (one conflict-free ds_read_b64 returns the match words of 4 cells), so the only algorithmic VALU work left
+# is the add: v_pk_add_i16 with clamp, 2 cells per lane-instruction; gfx950 has no wider saturating add.
+# v_pk_add_i16 belongs to the HALF-rate VALU class: a wave64 instruction holds its SIMD for 4 cycles (16 lanes/clk),
+# measured with tools/valu_rates.hip (profiles/r01_valu_rates_4waves_per_simd.txt; the full-rate class -- v_add_u32,
+# v_and_b32, v_fma_f32 ... -- has no packed saturating add).  Peak for this class:
+# 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3e12 lane-instructions/s = 78.6e12 int16 adds/s.
 PEAK_TIOPS_I16 = 78.6
-PEAK_TIOPS_I16_FULL_RATE_CLASS = 157.3  # what the same count would be against 32 lanes/clk (fp32-FMA class)
-OPS_PER_CELL = 2                       # one 4:1 score select + one saturating add
+PEAK_TIOPS_I16_FULL_RATE_CLASS = 157.3  # the same count against 32 lanes/clk (the fp32-FMA class), for reference
+OPS_PER_CELL = 1                        # one int16 saturating add per cell on the VALU
+# LDS side of the same kernel: 8 bytes (one ds_read_b64) per lane per 4 cells = 2 B/cell;
+# peak 256 B/clk/CU (MI355X_MICROARCH.md, LDS table) x 256 CUs x 2.4 GHz = 157.3 TB/s.
+LDS_BYTES_PER_CELL = 2
+LDS_PEAK_TBS = 157.3
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per launch of ssv_diag_kernel on the default workload, from the separate rocprofv3 --pmc
 # passes in profiles/r01_pmc_c2.csv: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 with the gfx950 FETCH_SIZE
 # correction of MI355X_MICROARCH.md (uncalibrated for 8-byte-per-lane loads: an upper bound).
-PMC_TRAFFIC_C2_BYTES = (2 * 14162.1 + 10146.3) * 1024
+PMC_TRAFFIC_C2_BYTES = (2 * 14100.0 + 10310.0) * 1024
 
 
 def plant_packed(packed: np.ndarray, consensus: np.ndarray, nreal: int, every=1_000_000, length=300, sub=0.15,
@@ -212,8 +217,8 @@ def main():
         nhits = int(merged.numel())
         hits_np = merged.cpu().numpy().view(np.uint64)
         # algorithmic HBM bytes of this rank's launch: its share of the packed sequence once, the
-        # widened model once (8 B/row), 8 B per hit
-        algo_bytes = ncols / 4 / world + 8 * nrows + 8 * found
+        # model once (4 B/row), 8 B per hit
+        algo_bytes = ncols / 4 / world + 4 * nrows + 8 * found
         kernel_s = ssv_ms / 1e3
         achieved_tiops = my_cells * OPS_PER_CELL / kernel_s / 1e12
         out = {
@@ -235,10 +240,14 @@ def main():
                        "gcups_kernel_only": round(my_cells / kernel_s / 1e9, 1)},
             "roofline": {
                 "bound": "valu", "achieved": round(achieved_tiops, 2), "peak": PEAK_TIOPS_I16,
-                "unit": "Tiop/s (int16 ops; 2 per cell)", "frac": round(achieved_tiops / PEAK_TIOPS_I16, 4),
+                "unit": "Tiop/s (int16 saturating adds, 1 per cell; the score select is served by LDS)",
+                "frac": round(achieved_tiops / PEAK_TIOPS_I16, 4),
                 "frac_vs_full_rate_class_peak": round(achieved_tiops / PEAK_TIOPS_I16_FULL_RATE_CLASS, 4),
                 "traffic": args.traffic_bytes if args.traffic_bytes is not None else (
                     PMC_TRAFFIC_C2_BYTES if (world == 1 and nrows == ROWS and args.columns_per_gpu == COLUMNS_PER_GPU) else None),
+                "lds": {"bound": "lds", "achieved": round(my_cells * LDS_BYTES_PER_CELL / kernel_s / 1e12, 2),
+                        "peak": LDS_PEAK_TBS, "unit": "TB/s (ds_read_b64, 2 B per cell)",
+                        "frac": round(my_cells * LDS_BYTES_PER_CELL / kernel_s / 1e12 / LDS_PEAK_TBS, 4)},
                 "hbm": {"bound": "hbm", "achieved": round(algo_bytes / kernel_s / 1e9, 3), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(algo_bytes / kernel_s / 1e9 / HBM_PEAK_GBS, 6),
                         "algorithmic_bytes_per_launch": int(algo_bytes)},
