@@ -239,9 +239,13 @@ __device__ __forceinline__ void step_pair(uint32_t (&cur)[kRegs], uint32_t (&nxt
         any |= nxt[i];
     }
     if (__builtin_expect(__any((any & kCrossedBits) != 0), 0)) {
-        const uint32_t mask0 = crossed_mask(cur);                     // crossed 256 on the first step
-        const uint32_t mask1 = crossed_mask(nxt) & ~mask0;            // on the second (a first-step mark is still on nxt)
-        if (__any(mask0 != 0)) {
+        uint32_t any_first = 0;
+#pragma unroll
+        for (int i = 0; i < kRegs; i++) any_first |= cur[i];
+        uint32_t mask0 = 0, mask1;
+        if (__any((any_first & kCrossedBits) != 0)) {
+            mask0 = crossed_mask(cur);                                // crossed 256 on the first step
+            mask1 = crossed_mask(nxt) & ~mask0;                       // on the second (a first-step mark is still on nxt)
             // a cell that crossed on the first step restarts from 0 (SoftSsv.cpp:43-44): redo its second step
 #pragma unroll
             for (int i = 0; i < kRegs; i++) {
@@ -252,11 +256,10 @@ __device__ __forceinline__ void step_pair(uint32_t (&cur)[kRegs], uint32_t (&nxt
                 nxt[i] = (repl & sx) | (nxt[i] & ~sx);
             }
         } else {
+            // only second-step crossings: those cells hold exactly 0x7fff; + 1 makes it 0x8000 = score 0
+            mask1 = crossed_mask(nxt);
 #pragma unroll
-            for (int i = 0; i < kRegs; i++) {
-                const uint32_t sx = (nxt[i] & kCrossedBits) * 0xffffu;
-                nxt[i] = (kScoreZero & sx) | (nxt[i] & ~sx);            // crossed cells restart at 0
-            }
+            for (int i = 0; i < kRegs; i++) nxt[i] += nxt[i] & kCrossedBits;
         }
         constexpr int r = (2 * P) % kMaskSteps;
         masks[r * 64 + lane] = mask0;
@@ -306,16 +309,12 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
 
     // LDS byte address of this wave's tables (a multiple of 128: code*8 is OR-ed into it)
     const uint32_t table_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds->table;
-    // this lane's share of the table build: symbol-pair code `entry` of step pairs pair_group, +4, +8, +12
-    const uint32_t entry = lane & 15, pair_group = lane >> 4;
-    const uint32_t sel_first = word_selector(entry & 3u), sel_second = word_selector(entry >> 2);
-    const uint32_t my_entry_addr = table_base + pair_group * kPairStride + entry * 8;
-    if (entry == 0) {     // the "outside the matrix" entries never change
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-            *(lds_words_out_t)(uintptr_t)(table_base + (pair_group + 4 * m) * kPairStride + kOutsideCode) =
-                u32x2{kOutsideWord, kOutsideWord};
-    }
+    // this lane's share of the table build: the four entries (a, b) with b = lane & 3 of step pair lane >> 2
+    const uint32_t my_pair = lane >> 2, my_b = lane & 3;
+    const uint32_t sel_second = word_selector(my_b);
+    const uint32_t my_entries_addr = table_base + my_pair * kPairStride + my_b * 32;
+    if (my_b == 0)        // the "outside the matrix" entry of each table never changes
+        *(lds_words_out_t)(uintptr_t)(table_base + my_pair * kPairStride + kOutsideCode) = u32x2{kOutsideWord, kOutsideWord};
 
     uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_pair)
 #pragma unroll
@@ -325,10 +324,13 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
     // table entry of the symbol pair (j+2k, j+2k+1).  The upper half of one chunk's window is the lower half of the
     // next, so each chunk expands only the 32 new symbols.
     uint32_t C[32];
-    auto expand = [&](int64_t rel) {     // symbols [dl+rel, dl+rel+32) -> C[16 .. 32); rel is wave-uniform
+    auto fetch_symbols = [&](int64_t rel) -> uint2 {     // symbols [dl+rel, dl+rel+32); rel is wave-uniform
         const bool edge = (d0 + rel < 0) || (d0 + rel + kTileDiags > nsymbols);   // the wave's 2048 positions
+        return load_symbols(seq, nsymbols, dl + rel, edge);
+    };
+    auto expand = [&](const uint2 packed, int64_t rel) {  // -> C[16 .. 32)
+        const bool edge = (d0 + rel < 0) || (d0 + rel + kTileDiags > nsymbols);
         const int64_t pos = dl + rel;
-        const uint2 packed = load_symbols(seq, nsymbols, pos, edge);
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const uint32_t w = k < 8 ? packed.x : packed.y;
@@ -345,31 +347,37 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
             }
         }
     };
-    // the chunk's 16 step-pair tables: entry (a,b) of pair P = { word(step 2P, a), word(step 2P+1, b) } with
-    // word(t, a) = (M[t][a] << 8) | (M[t-1][a] << 24); rows[] is shifted by one, so rows[t] is M[t-1]
-    auto build_tables = [&](int64_t p0) {
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const uint32_t* r = rows + p0 + 2 * (pair_group + 4 * m);
-            const uint32_t r0 = r[0], r1 = r[1], r2 = r[2];
-            u32x2 e;
-            e.x = __builtin_amdgcn_perm(r0, r1, sel_first);
-            e.y = __builtin_amdgcn_perm(r1, r2, sel_second);
-            *(lds_words_out_t)(uintptr_t)(my_entry_addr + 4 * m * kPairStride) = e;
-        }
+    // A chunk's 16 step-pair tables: entry (a,b) of pair P = { word(step 2P, a), word(step 2P+1, b) } with
+    // word(t, a) = (M[t][a] << 8) | (M[t-1][a] << 24); rows[] is shifted by one, so rows[t] is M[t-1].
+    // Four lanes share a step pair: they fetch its three model rows and each writes the entries of one b.
+    struct ModelRows { uint32_t r0, r1, r2; };
+    auto fetch_rows = [&](int64_t p0) -> ModelRows {
+        const uint32_t* r = rows + p0 + 2 * my_pair;
+        return ModelRows{r[0], r[1], r[2]};
     };
-    expand(p_lo);
+    auto build_tables = [&](const ModelRows r) {
+        const uint32_t second = __builtin_amdgcn_perm(r.r1, r.r2, sel_second);
+        const lds_words_out_t out = (lds_words_out_t)(uintptr_t)my_entries_addr;
+#pragma unroll
+        for (int a = 0; a < 4; a++) out[a] = u32x2{__builtin_amdgcn_perm(r.r0, r.r1, word_selector(a)), second};
+    };
+    expand(fetch_symbols(p_lo), p_lo);
+    // the global loads of a chunk are issued one chunk ahead, so their latency hides behind 16 step pairs
+    ModelRows next_rows = fetch_rows(p_lo);
+    uint2 next_symbols = fetch_symbols(p_lo + 32);
 
     for (int64_t p0 = p_lo; p0 < p_hi; p0 += kChunkRows) {
         // abort: a device word, read past the caches every 2048 rows (never on a wave's first chunk, so
         // short models pay nothing)
         if (abort_flag && ((p0 & 2047) == 0) && p0 != p_lo &&
             __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
-        build_tables(p0);
+        build_tables(next_rows);
         // slide the window by 32 symbols
 #pragma unroll
         for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-        expand(p0 + 32);
+        expand(next_symbols, p0 + 32);
+        next_rows = fetch_rows(p0 + kChunkRows);              // rows[] has kModelSlack words behind the model
+        next_symbols = fetch_symbols(p0 + kChunkRows + 32);
 
         uint32_t steps_with_hits = 0;   // wave-uniform
         step_pairs<0>(x, x2, C, lds->masks, steps_with_hits, lane, std::make_integer_sequence<int, kChunkPairs / 2>{});
@@ -380,7 +388,7 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
     }
     if (p_hi == (int64_t)nrows_padded) {
         // the high cells run one row behind: one more step gives them the model's last row
-        build_tables(p_hi);
+        build_tables(next_rows);                               // fetched for p_hi by the last chunk
 #pragma unroll
         for (int k = 0; k < 16; k++) C[k] = C[k + 16];
         uint32_t steps_with_hits = 0;
