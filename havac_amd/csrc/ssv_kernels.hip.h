@@ -282,7 +282,7 @@ __device__ __forceinline__ void step_pairs(uint32_t (&a)[kRegs], uint32_t (&b)[k
 // yields (row_t[a] << 8) | (row_tm1[a] << 24)
 __device__ __forceinline__ uint32_t word_selector(uint32_t a) { return 0x040c000cu + a * 0x01000100u; }
 
-__global__ __launch_bounds__(64 * kWavesPerBlock, 4)   // 4 waves per SIMD: at most 128 VGPRs
+__global__ __launch_bounds__(64 * kWavesPerBlock, 4)   // 4 waves per SIMD (<= 128 VGPRs): 3 is 6 % slower, 5 spills badly
 void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, const uint32_t* __restrict__ rows,
                      const uint32_t nrows_padded, const int64_t first_diag, const uint32_t tile_begin,
                      const uint32_t tile_end, uint64_t* __restrict__ hits, unsigned long long* __restrict__ hit_count,
