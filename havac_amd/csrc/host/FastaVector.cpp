@@ -69,7 +69,7 @@ FastaVectorReturnCode fastaVectorReadFasta(const char *path, FastaVector *fv) {
     if (!f) return FASTA_VECTOR_FILE_OPEN_FAIL;
     const char zero = '\0';
     bool inRecord = false, inHeader = false, lineStart = true;
-    static const size_t kBuf = 1 << 16;
+    static const size_t kBuf = 1 << 20;
     char *buf = static_cast<char *>(std::malloc(kBuf));
     if (!buf) { std::fclose(f); return FASTA_VECTOR_ALLOCATION_FAIL; }
     FastaVectorReturnCode rc = FASTA_VECTOR_OK;
@@ -78,35 +78,63 @@ FastaVectorReturnCode fastaVectorReadFasta(const char *path, FastaVector *fv) {
         inRecord = false;
         return push(fv->sequence, &zero, 1) && pushMeta(fv->metadata, {fv->header.count, fv->sequence.count});
     };
+    // Works a line segment at a time: memchr finds the end of the line inside the buffer, residues are
+    // appended in bulk and blanks are squeezed out afterwards only if the segment had any.
     size_t got;
     while (rc == FASTA_VECTOR_OK && (got = std::fread(buf, 1, kBuf, f)) > 0) {
-        for (size_t i = 0; i < got && rc == FASTA_VECTOR_OK; i++) {
-            const char c = buf[i];
+        size_t i = 0;
+        while (i < got && rc == FASTA_VECTOR_OK) {
+            const char *nl = static_cast<const char *>(std::memchr(buf + i, '\n', got - i));
+            const size_t end = nl ? (size_t)(nl - buf) : got;       // segment [i, end), newline (if any) at end
             if (inHeader) {
-                if (c == '\n') {
+                size_t n = end - i;
+                if (!push(fv->header, buf + i, n)) { rc = FASTA_VECTOR_ALLOCATION_FAIL; break; }
+                // drop carriage returns from what was just appended
+                size_t w = fv->header.count - n;
+                for (size_t r = w; r < fv->header.count; r++)
+                    if (fv->header.charData[r] != '\r') fv->header.charData[w++] = fv->header.charData[r];
+                fv->header.count = w;
+                if (nl) {
                     inHeader = false;
                     lineStart = true;
                     if (!push(fv->header, &zero, 1)) rc = FASTA_VECTOR_ALLOCATION_FAIL;
-                } else if (c != '\r') {
-                    if (!push(fv->header, &c, 1)) rc = FASTA_VECTOR_ALLOCATION_FAIL;
                 }
-                continue;
-            }
-            if (c == '\n') { lineStart = true; continue; }
-            if (lineStart && c == '>') {
-                if (!closeRecord()) rc = FASTA_VECTOR_ALLOCATION_FAIL;
-                inRecord = true;
-                inHeader = true;
+            } else if (i < end) {
+                if (lineStart && buf[i] == '>') {
+                    if (!closeRecord()) { rc = FASTA_VECTOR_ALLOCATION_FAIL; break; }
+                    inRecord = true;
+                    inHeader = true;
+                    lineStart = false;
+                    i++;                      // past '>' and handle the rest of the segment as header text
+                    continue;
+                }
                 lineStart = false;
-                continue;
+                size_t n = end - i;
+                if (!inRecord) {              // residues before any header: an unnamed record
+                    bool any = false;
+                    for (size_t r = i; r < end && !any; r++) any = !(buf[r] == '\r' || buf[r] == ' ' || buf[r] == '\t');
+                    if (any) {
+                        inRecord = true;
+                        if (!push(fv->header, &zero, 1)) { rc = FASTA_VECTOR_ALLOCATION_FAIL; break; }
+                    }
+                }
+                if (inRecord) {
+                    if (!push(fv->sequence, buf + i, n)) { rc = FASTA_VECTOR_ALLOCATION_FAIL; break; }
+                    const char *seg = fv->sequence.charData + fv->sequence.count - n;
+                    if (std::memchr(seg, '\r', n) || std::memchr(seg, ' ', n) || std::memchr(seg, '\t', n)) {
+                        size_t w = fv->sequence.count - n;
+                        for (size_t r = w; r < fv->sequence.count; r++) {
+                            const char c = fv->sequence.charData[r];
+                            if (c != '\r' && c != ' ' && c != '\t') fv->sequence.charData[w++] = c;
+                        }
+                        fv->sequence.count = w;
+                    }
+                }
+                if (nl) lineStart = true;
+            } else if (nl) {
+                lineStart = true;             // empty line
             }
-            lineStart = false;
-            if (c == '\r' || c == ' ' || c == '\t') continue;
-            if (!inRecord) {   // residues before any header: an unnamed record
-                inRecord = true;
-                if (!push(fv->header, &zero, 1)) rc = FASTA_VECTOR_ALLOCATION_FAIL;
-            }
-            if (!push(fv->sequence, &c, 1)) rc = FASTA_VECTOR_ALLOCATION_FAIL;
+            i = nl ? end + 1 : got;
         }
     }
     if (rc == FASTA_VECTOR_OK && std::ferror(f)) rc = FASTA_VECTOR_FILE_READ_FAIL;

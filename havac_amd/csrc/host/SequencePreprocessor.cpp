@@ -18,20 +18,50 @@ namespace {
 constexpr uint32_t kSegment = 12288;   // NUM_CELL_PROCESSORS, device/PublicDefines.h:18-22
 }
 
+namespace {
+// 0..3 for acgtACGT, 0xff for every character that draws from rand()
+struct CodeTable {
+    uint8_t code[256];
+    CodeTable() {
+        for (int i = 0; i < 256; i++) code[i] = 0xff;
+        code[(int)'a'] = code[(int)'A'] = 0;
+        code[(int)'c'] = code[(int)'C'] = 1;
+        code[(int)'g'] = code[(int)'G'] = 2;
+        code[(int)'t'] = code[(int)'T'] = 3;
+    }
+};
+const CodeTable kCodes;
+}  // namespace
+
 SequencePreprocessor::SequencePreprocessor(FastaVector *fastaVector) {
     originalLength_ = (uint32_t)fastaVector->sequence.count;
     segments_ = (originalLength_ + (kSegment - 1)) / kSegment;
     symbols_ = segments_ * kSegment;
     bytes_ = symbols_ / 4;
     packed_.assign(bytes_, 0);
-    const char *chars = fastaVector->sequence.charData;
-    for (uint32_t i = 0; i < fastaVector->sequence.count; i++) {
-        const uint8_t code = getCompressedSymbol(chars[i]);
+    const unsigned char *chars = reinterpret_cast<const unsigned char *>(fastaVector->sequence.charData);
+    const uint32_t count = (uint32_t)fastaVector->sequence.count;
+    // Same result as the reference's one-character-at-a-time loop (host/sequence/SequencePreprocessor.cpp:37-59),
+    // produced a byte (four characters) at a time when all four are plain nucleotides; any other character goes
+    // through the reference-shaped path, in order, so rand() is called exactly as often and in the same order.
+    auto slow = [&](uint32_t i) {
+        const uint8_t code = getCompressedSymbol((char)chars[i]);
         const uint32_t byte = i / 4;
         const uint8_t shift = (uint8_t)((i % 4) * 2);
         packed_[byte] &= (uint8_t)~(uint8_t)(0x3u << shift);     // clear this symbol's field (:52-54)
-        packed_[byte] |= (uint8_t)(code << shift);               // the unmasked OR of :56-57
+        packed_[byte] |= (uint8_t)(code << shift);               // the unmasked OR of :56-57 ('Y' may spill upward)
+    };
+    uint32_t i = 0;
+    for (; i + 4 <= count; i += 4) {
+        const uint8_t a = kCodes.code[chars[i]], b = kCodes.code[chars[i + 1]], c = kCodes.code[chars[i + 2]],
+                      d = kCodes.code[chars[i + 3]];
+        if ((a | b | c | d) <= 3) {
+            packed_[i / 4] = (uint8_t)(a | (b << 2) | (c << 4) | (d << 6));
+        } else {
+            slow(i); slow(i + 1); slow(i + 2); slow(i + 3);
+        }
     }
+    for (; i < count; i++) slow(i);
 }
 
 uint8_t SequencePreprocessor::getCompressedSymbol(const char c) {

@@ -175,3 +175,37 @@ def test_resolver_maps_records_to_hits(tmp_path, oracle):
     got = [(h.sequencePosition, h.sequenceIndex, h.phmmPosition, h.phmmIndex) for h in hits]
     assert got == [(0, 0, 0, 0), (100, 0, 29, 0), (0, 1, 0, 1), (20000, 1, 39, 1), (0, 2, 5, 0), (6, 2, 5, 0), (7, 2, 5, 0)]
     assert hits[1].toString() == "sequence $0, position 100; phmm #0 position 29"
+
+
+def test_fasta_reader_against_a_plain_python_parse(tmp_path):
+    """Long lines (crossing the reader's 1 MiB buffer), CRLF, blank lines, blanks inside lines, no final newline."""
+    rng = np.random.default_rng(9)
+    alphabet = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
+    records, text = [], []
+    for k in range(7):
+        n = int(rng.integers(0, 1_500_000)) if k != 3 else 0
+        seq = alphabet[rng.integers(0, alphabet.size, size=n)].tobytes().decode()
+        records.append(seq)
+        text.append(f">rec{k} some description\r\n" if k % 2 else f">rec{k}\n")
+        width = [60, 70, 1_200_000, 80, 61, 999_983, 50][k]
+        for i in range(0, n, width):
+            line = seq[i:i + width]
+            if k == 4 and i == 0 and len(line) > 10:
+                line = line[:5] + " \t" + line[5:]          # blanks are squeezed out
+            text.append(line + ("\r\n" if k % 2 else "\n"))
+        if k == 2:
+            text.append("\n\n")
+    p = tmp_path / "big.fa"
+    p.write_text("".join(text).rstrip("\n"))
+    packed, nchars, nrec = havac.pack_fasta(str(p), seed=3)
+    assert nrec == 7
+    assert nchars == sum(len(r) + 1 for r in records)
+    sym = synth.unpack_2bit(packed)
+    lut = np.full(256, 255, np.uint8)
+    for ch, v in zip(b"ACGTacgt", [0, 1, 2, 3, 0, 1, 2, 3]):
+        lut[ch] = v
+    at = 0
+    for r in records:
+        want = lut[np.frombuffer(r.encode(), dtype=np.uint8)]
+        assert np.array_equal(sym[at:at + len(r)], want)
+        at += len(r) + 1                                    # the terminator column holds a random nucleotide
