@@ -205,3 +205,17 @@ def test_havac_benchmark_binary(tmp_path):
     assert out.returncode == 0, out.stderr
     for line in ("verified hits.", "havac build time", "havac load time", "havac run time", "havac verify time", "total time taken"):
         assert line in out.stdout
+
+
+def test_limits_of_the_record_format(client):
+    """rows < 2^24 (24-bit row field, device/HavacHls.hpp:19); packed sequence < 4 GiB (HavacHwClient.cpp:92-97);
+    model bytes < 1 GiB (:121-125).  All refused before anything is uploaded."""
+    from havac_amd.hw_client import LengthError
+    with pytest.raises(LengthError, match="less than 4GiB"):
+        client.writeSequence(np.zeros(-(-(4 << 30) // 3072) * 3072, np.uint8))   # whole segments, just over 4 GiB
+    with pytest.raises(LengthError, match="model length must be less than"):
+        client.writePhmm(np.zeros(1 << 30, np.int8))
+    client.writeSequence(np.zeros(synth.SEGMENT // 4, np.uint8))
+    client.writePhmm(np.zeros(((1 << 24) * 4,), np.int8))          # 2^24 rows: one more than the record can name
+    with pytest.raises(LengthError, match="below 2\\^24"):
+        client.invokeHavacSsvAsync()

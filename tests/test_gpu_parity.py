@@ -64,3 +64,32 @@ def test_random_against_oracle(client, oracle, nrows, nseg, kind, seed):
     client.setHitCapacity(max(1 << 20, want.size + 16))
     got = run(client, synth.pack_2bit(sym), model)
     assert np.array_equal(got, want), first_difference(got, want, oracle)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_extreme_models(client, oracle, seed):
+    """Scores at the int8 extremes and crossings on consecutive rows: both steps of a pair, both cells of a
+    register, repairs after a first-step crossing, saturation back down to zero."""
+    rng = np.random.default_rng(1000 + seed)
+    nrows = int(rng.integers(33, 200))
+    choices = [np.array([-128, 127]), np.array([-128, -1, 0, 1, 127]), np.array([126, 127, -127, -128]),
+               np.array([64, 127, -64]), np.array([127]), np.array([-128, 127, 127, 127])][seed]
+    model = rng.choice(choices, size=(nrows, 4)).astype(np.int8)
+    sym = synth.random_symbols(2 * synth.SEGMENT - 77, seed=2000 + seed)
+    want = oracle.ssv_mt(sym, model)
+    client.setHitCapacity(max(1 << 20, want.size + 16))
+    got = run(client, synth.pack_2bit(sym), model)
+    assert got.size == want.size and np.array_equal(got, want), first_difference(got, want, oracle)
+
+
+def test_rows_exactly_at_chunk_multiples(client, oracle):
+    """Model lengths 32k-1, 32k, 32k+1 around the kernel's 32-row chunk: the last row belongs to the lagging cells."""
+    rng = np.random.default_rng(77)
+    sym = synth.random_symbols(synth.SEGMENT, seed=78)
+    for nrows in (31, 32, 33, 63, 64, 65, 96):
+        model = rng.integers(-40, 128, size=(nrows, 4)).astype(np.int8)
+        model[-1] = 127                                   # make the very last row decide hits
+        want = oracle.ssv(sym, model)
+        client.setHitCapacity(max(1 << 20, want.size + 16))
+        got = run(client, synth.pack_2bit(sym), model)
+        assert np.array_equal(got, want), (nrows, first_difference(got, want, oracle))
