@@ -42,8 +42,8 @@ SIGNATURES = {
     "havac_ssv_sort_hits": (C.c_int, [_vp, C.c_void_p, C.c_uint64, C.c_void_p]),
     "havac_ssv_last_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "havac_ssv_shard_cells": (C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
-    "havac_ssv_shard_diagonals": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
-                                            C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "havac_ssv_shard_columns": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32,
+                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "havac_ssv_ctx_last_error": (C.c_char_p, [_vp]),
     "havac_dev_version": (C.c_char_p, []),
 }

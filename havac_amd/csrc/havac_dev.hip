@@ -57,44 +57,24 @@ Tiling make_tiling(uint64_t nsymbols, uint32_t nrows) {
     return t;
 }
 
-// rows a tile actually sweeps (same arithmetic as the kernel's p_lo / p_hi)
-int64_t tile_rows(const Tiling& t, uint64_t nsymbols, uint32_t tile) {
-    int64_t d0 = t.first_diag + (int64_t)tile * kTileDiags;
-    int64_t lo = -d0 - kTileDiags;
-    if (lo < 0) lo = 0;
-    int64_t hi = (int64_t)nsymbols - d0;
-    if (hi > (int64_t)t.nrows_padded) hi = t.nrows_padded;
-    return hi > lo ? hi - lo : 0;
+// Shards are runs of whole 12288-column segments: shard k of n owns columns [begin, end).  A shard computes
+// the diagonals that reach its columns (a left halo of nrows-1 columns is recomputed) and
+// reports only hits inside its columns, so the shards' ordered lists concatenate to the ordered whole.
+void shard_columns(uint64_t nsymbols, uint32_t shard_index, uint32_t shard_count, uint64_t* begin, uint64_t* end) {
+    const uint64_t nseg = nsymbols / HAVAC_SEGMENT_COLUMNS;
+    *begin = nseg * shard_index / shard_count * HAVAC_SEGMENT_COLUMNS;
+    *end = nseg * (shard_index + 1) / shard_count * HAVAC_SEGMENT_COLUMNS;
 }
 
-// split tiles into shard_count runs of nearly equal swept rows
-void shard_tiles(const Tiling& t, uint64_t nsymbols, uint32_t shard_index, uint32_t shard_count,
-                 uint32_t* begin, uint32_t* end) {
-    if (shard_count <= 1) { *begin = 0; *end = t.ntiles; return; }
-    std::vector<int64_t> prefix(t.ntiles + 1, 0);
-    for (uint32_t i = 0; i < t.ntiles; i++) prefix[i + 1] = prefix[i] + tile_rows(t, nsymbols, i);
-    auto cut = [&](uint32_t k) -> uint32_t {
-        if (k == 0) return 0;
-        if (k >= shard_count) return t.ntiles;
-        int64_t target = prefix[t.ntiles] / shard_count * k;
-        uint32_t lo = 0, hi = t.ntiles;
-        while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (prefix[mid] < target) lo = mid + 1; else hi = mid; }
-        return lo;
-    };
-    *begin = cut(shard_index);
-    *end = cut(shard_index + 1);
-}
-
-// cells (p, s) of the real matrix with s - p < D
-uint64_t cells_below_diag(uint64_t nsymbols, uint32_t nrows, int64_t D) {
-    uint64_t total = 0;
-    for (uint32_t p = 0; p < nrows; p++) {
-        int64_t c = D + (int64_t)p;
-        if (c < 0) c = 0;
-        if (c > (int64_t)nsymbols) c = (int64_t)nsymbols;
-        total += (uint64_t)c;
-    }
-    return total;
+// tiles (runs of 2048 diagonals) that contain a cell of columns [begin, end)
+void shard_tiles(const Tiling& t, uint32_t nrows, uint64_t col_begin, uint64_t col_end, uint32_t* tb, uint32_t* te) {
+    if (col_end <= col_begin) { *tb = *te = 0; return; }
+    // diagonal d = column - row, stored relative to first_diag = -nrows_padded
+    const uint64_t lowest = col_begin + t.nrows_padded - (nrows - 1);      // column col_begin on the last row
+    const uint64_t highest = col_end - 1 + t.nrows_padded;                 // column col_end-1 on row 0
+    *tb = (uint32_t)(lowest / kTileDiags);
+    *te = (uint32_t)(highest / kTileDiags) + 1;
+    if (*te > t.ntiles) *te = t.ntiles;
 }
 
 }  // namespace
@@ -154,24 +134,18 @@ extern "C" const char* havac_ssv_ctx_last_error(havac_ssv_ctx* c) { return c ? c
 
 extern "C" uint64_t havac_ssv_shard_cells(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index,
                                           uint32_t shard_count) {
-    if (nrows == 0 || nsymbols == 0) return 0;
-    if (shard_count <= 1) return nsymbols * (uint64_t)nrows;
-    Tiling t = make_tiling(nsymbols, nrows);
-    uint32_t b, e;
-    shard_tiles(t, nsymbols, shard_index, shard_count, &b, &e);
-    int64_t D0 = t.first_diag + (int64_t)b * kTileDiags, D1 = t.first_diag + (int64_t)e * kTileDiags;
-    return cells_below_diag(nsymbols, nrows, D1) - cells_below_diag(nsymbols, nrows, D0);
+    if (nrows == 0 || nsymbols == 0 || shard_count == 0 || shard_index >= shard_count) return 0;
+    uint64_t b, e;
+    shard_columns(nsymbols, shard_index, shard_count, &b, &e);
+    return (e - b) * (uint64_t)nrows;
 }
 
-extern "C" int havac_ssv_shard_diagonals(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index,
-                                         uint32_t shard_count, int64_t* diag_begin, int64_t* diag_end) {
-    if (!diag_begin || !diag_end || shard_count == 0 || shard_index >= shard_count || nrows == 0 || nsymbols == 0)
+extern "C" int havac_ssv_shard_columns(uint64_t nsymbols, uint32_t shard_index, uint32_t shard_count,
+                                       uint64_t* col_begin, uint64_t* col_end) {
+    if (!col_begin || !col_end || shard_count == 0 || shard_index >= shard_count || nsymbols == 0 ||
+        nsymbols % HAVAC_SEGMENT_COLUMNS != 0)
         return HAVAC_E_ARGUMENT;
-    Tiling t = make_tiling(nsymbols, nrows);
-    uint32_t b, e;
-    shard_tiles(t, nsymbols, shard_index, shard_count, &b, &e);
-    *diag_begin = t.first_diag + (int64_t)b * kTileDiags;
-    *diag_end = t.first_diag + (int64_t)e * kTileDiags;
+    shard_columns(nsymbols, shard_index, shard_count, col_begin, col_end);
     return HAVAC_OK;
 }
 
@@ -216,8 +190,10 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         HIP_TRY(c->err, hipMalloc(&c->rows8, (size_t)model_words * sizeof(uint32_t)));
         c->rows8_rows = model_words;
     }
+    uint64_t col_begin, col_end;
+    shard_columns(nsymbols, shard_index, shard_count, &col_begin, &col_end);
     uint32_t tb, te;
-    shard_tiles(t, nsymbols, shard_index, shard_count, &tb, &te);
+    shard_tiles(t, nrows, col_begin, col_end, &tb, &te);
 
     HIP_TRY(c->err, hipEventRecord(c->ev[0], stream));
     HIP_TRY(c->err, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), stream));
@@ -228,7 +204,7 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         uint32_t nblocks = (te - tb + kWavesPerBlock - 1) / kWavesPerBlock;
         hipLaunchKernelGGL(ssv_diag_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream,
                            d_sequence, (int64_t)nsymbols, (const uint32_t*)c->rows8, t.nrows_padded, t.first_diag,
-                           tb, te, d_hits, c->d_count, hit_capacity, d_abort_flag);
+                           tb, te, (int64_t)col_begin, (int64_t)col_end, d_hits, c->d_count, hit_capacity, d_abort_flag);
     }
     HIP_TRY(c->err, hipEventRecord(c->ev[2], stream));
     HIP_TRY(c->err, hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
@@ -326,7 +302,8 @@ struct havac_dev {
     std::string err;
 };
 
-static const uint64_t kDefaultHitCapacity = 16ull << 20;
+// the reference's fixed hit buffer: 14 * 256 MiB = 3.5 GiB = 469,762,048 records (host/HavacHwClient.hpp:94)
+static const uint64_t kDefaultHitCapacity = 14ull * 256ull * 1024ull * 1024ull / sizeof(uint64_t);
 
 static int dev_alloc_hits(havac_dev* d, uint64_t cap) {
     if (d->d_hits) { (void)hipFree(d->d_hits); d->d_hits = nullptr; d->hit_capacity = 0; }

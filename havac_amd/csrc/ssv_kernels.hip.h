@@ -147,6 +147,7 @@ struct HitSink {
     unsigned long long* hit_count; // records found so far (may run past capacity)
     uint64_t hit_capacity;
     WaveLds* lds;
+    int64_t col_begin, col_end;    // only hits in these columns are reported (the shard's own columns)
 };
 
 __device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t staged, int lane) {
@@ -183,13 +184,17 @@ __device__ __noinline__ uint32_t drain_steps(const HitSink sink, uint32_t staged
             const int src = __builtin_ctzll(lanes);
             lanes &= lanes - 1;
             const uint32_t m = __builtin_amdgcn_readlane(mask, src);
-            if (lane < 32 && ((m >> lane) & 1u)) {
-                const uint32_t pos = staged + __popc(m & ((1u << lane) - 1u));
-                const int reg = 2 * (lane & 7) + (lane >> 4);
-                const int high = (lane >> 3) & 1;
-                sink.lds->stage[pos] = hit_key(t - high, (uint64_t)(wave_diag0 + 32 * src + 2 * reg + (int64_t)t));
+            // lane q < 32 looks at bit q: register 2*(q & 7) + (q >> 4), cell (q >> 3) & 1
+            const int reg = 2 * (lane & 7) + ((lane >> 4) & 1);
+            const int high = (lane >> 3) & 1;
+            const int64_t column = wave_diag0 + 32 * src + 2 * reg + (int64_t)t;
+            const bool mine = lane < 32 && ((m >> lane) & 1u) && column >= sink.col_begin && column < sink.col_end;
+            const unsigned long long writers = __ballot(mine);      // halo columns belong to the neighbouring shard
+            if (mine) {
+                const uint32_t pos = staged + __popcll(writers & ((1ull << lane) - 1ull));
+                sink.lds->stage[pos] = hit_key(t - high, (uint64_t)column);
             }
-            staged += __popc(m);
+            staged += __popcll(writers);
             if (staged > kHitStage - 32) staged = flush_hits(sink, staged, lane);
         }
     }
@@ -285,7 +290,8 @@ __device__ __forceinline__ uint32_t word_selector(uint32_t a) { return 0x040c000
 __global__ __launch_bounds__(64 * kWavesPerBlock, 4)   // 4 waves per SIMD (<= 128 VGPRs): 3 is 6 % slower, 5 spills badly
 void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, const uint32_t* __restrict__ rows,
                      const uint32_t nrows_padded, const int64_t first_diag, const uint32_t tile_begin,
-                     const uint32_t tile_end, uint64_t* __restrict__ hits, unsigned long long* __restrict__ hit_count,
+                     const uint32_t tile_end, const int64_t col_begin, const int64_t col_end,
+                     uint64_t* __restrict__ hits, unsigned long long* __restrict__ hit_count,
                      const uint64_t hit_capacity, const uint32_t* __restrict__ abort_flag) {
     __shared__ WaveLds wave_lds[kWavesPerBlock];
 
@@ -295,7 +301,7 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
     const uint32_t tile = tile_begin + blockIdx.x * kWavesPerBlock + wave;
     if (tile >= tile_end) return;
     WaveLds* const lds = &wave_lds[wave];
-    const HitSink sink{hits, hit_count, hit_capacity, lds};
+    const HitSink sink{hits, hit_count, hit_capacity, lds, col_begin, col_end};
     uint32_t staged = 0;          // wave-uniform
 
     const int64_t d0 = first_diag + (int64_t)tile * kTileDiags;     // wave's first diagonal
@@ -303,7 +309,7 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
     // steps whose cells of this tile can lie inside the matrix
     int64_t p_lo = -d0 - kTileDiags;                                // first chunk touching column >= 0
     if (p_lo < 0) p_lo = 0;
-    int64_t p_hi = nsymbols - d0;                                   // first chunk entirely at columns >= N
+    int64_t p_hi = col_end - d0;                                    // first chunk entirely right of the shard's columns
     if (p_hi > (int64_t)nrows_padded) p_hi = nrows_padded;
     if (p_lo >= p_hi) return;
 

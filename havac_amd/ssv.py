@@ -55,9 +55,10 @@ def shard_cells(nsymbols: int, nrows: int, shard_index: int = 0, shard_count: in
     return int(_lib.load().havac_ssv_shard_cells(nsymbols, nrows, shard_index, shard_count))
 
 
-def shard_diagonals(nsymbols: int, nrows: int, shard_index: int, shard_count: int):
-    b, e = C.c_int64(0), C.c_int64(0)
-    rc = _lib.load().havac_ssv_shard_diagonals(nsymbols, nrows, shard_index, shard_count, C.byref(b), C.byref(e))
+def shard_columns(nsymbols: int, shard_index: int, shard_count: int):
+    """-> (col_begin, col_end): the whole 12288-column segments shard `shard_index` of `shard_count` reports."""
+    b, e = C.c_uint64(0), C.c_uint64(0)
+    rc = _lib.load().havac_ssv_shard_columns(nsymbols, shard_index, shard_count, C.byref(b), C.byref(e))
     if rc != 0:
         raise_for(rc, "bad shard arguments")
     return b.value, e.value

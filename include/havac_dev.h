@@ -85,13 +85,13 @@ typedef struct havac_dev havac_dev;
 
 /* HavacHwClient::HavacHwClient(xclbin, kernelName, deviceIndex)
  * host/HavacHwClient.cpp:25-31.  There is no bitstream to load; the kernels
- * are inside the library.  Allocates the hit buffer (default capacity
- * 16 Mi records; see havac_dev_set_hit_capacity). */
+ * are inside the library.  Allocates the hit buffer with the reference's
+ * capacity, 14*256 MiB = 469,762,048 records (host/HavacHwClient.hpp:94);
+ * see havac_dev_set_hit_capacity. */
 int havac_dev_create(uint32_t device_index, havac_dev **out);
 void havac_dev_destroy(havac_dev *dev);
 
-/* Hit-buffer capacity in records; the reference's fixed value is
- * 14*256 MiB / 8 = 469,762,048 (host/HavacHwClient.hpp:94). */
+/* Change the hit-buffer capacity (records). */
 int havac_dev_set_hit_capacity(havac_dev *dev, uint64_t max_hits);
 
 /* HavacHwClient::writeSequence  host/HavacHwClient.cpp:78-110.
@@ -151,11 +151,12 @@ void havac_ssv_ctx_destroy(havac_ssv_ctx *ctx);
  *   d_sequence   2-bit packed sequence, 8-byte aligned, nsymbols % 12288 == 0
  *   d_phmm       int8 [nrows][4], 4-byte aligned
  *   shard_index, shard_count
- *                the DP matrix is cut along its diagonals into shard_count
- *                pieces of nearly equal work and only piece shard_index is
- *                computed (a cell depends on its own diagonal only, so no halo
- *                is recomputed and the union over shards is the whole answer);
- *                0,1 computes everything
+ *                the sequence is cut into shard_count runs of whole 12288-column
+ *                segments and only the hits in run shard_index are computed and
+ *                reported (the diagonals that reach the run are swept from their
+ *                start, i.e. a left halo of nrows-1 columns is recomputed; no
+ *                data is exchanged).  The shards' ordered lists, concatenated in
+ *                shard order, are the ordered list of the whole.  0,1 = everything
  *   d_hits       receives up to hit_capacity records
  *   d_abort_flag optional uint32 the kernel polls; nonzero stops the run
  *
@@ -181,16 +182,15 @@ int havac_ssv_sort_hits(havac_ssv_ctx *ctx, uint64_t *d_hits, uint64_t count, vo
  * SSV kernel and of the whole enqueue, from HIP events recorded on that stream. */
 int havac_ssv_last_ms(havac_ssv_ctx *ctx, float *ssv_kernel_ms, float *total_ms);
 
-/* Number of DP cells the given shard updates (defined cells only: padding
- * rows/diagonals outside the matrix are not counted), for GCUPS accounting. */
+/* Number of DP cells of the given shard (its columns x nrows; the recomputed
+ * halo is not counted), for GCUPS accounting. */
 uint64_t havac_ssv_shard_cells(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index,
                                uint32_t shard_count);
 
-/* The half-open range of diagonals (column - row) shard `shard_index` owns.
- * Host-only arithmetic (no device needed): lets a caller predict which hits a
- * shard will report. */
-int havac_ssv_shard_diagonals(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index,
-                              uint32_t shard_count, int64_t *diag_begin, int64_t *diag_end);
+/* The half-open range of columns shard `shard_index` owns (multiples of 12288).
+ * Host-only arithmetic (no device needed). */
+int havac_ssv_shard_columns(uint64_t nsymbols, uint32_t shard_index, uint32_t shard_count,
+                            uint64_t *col_begin, uint64_t *col_end);
 
 const char *havac_ssv_ctx_last_error(havac_ssv_ctx *ctx);
 

@@ -86,14 +86,14 @@ def test_product_never_touches_the_oracle():
 
 
 def test_shard_arithmetic_is_host_only():
-    """havac_ssv_shard_diagonals / shard_cells need no device: shards tile the diagonals exactly."""
-    from havac_amd.ssv import shard_cells, shard_diagonals
-    n, rows = 40 * 12288, 1000
-    for world in (1, 2, 3, 8):
-        spans = [shard_diagonals(n, rows, r, world) for r in range(world)]
-        assert spans[0][0] <= -(rows - 1) and spans[-1][1] >= n
+    """havac_ssv_shard_columns / shard_cells need no device: shards are runs of whole segments that tile the columns."""
+    from havac_amd.ssv import shard_cells, shard_columns
+    n, rows = 41 * 12288, 1000
+    for world in (1, 2, 3, 8, 41):
+        spans = [shard_columns(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        assert all(b % 12288 == 0 and e % 12288 == 0 and e > b for b, e in spans)
         assert sum(shard_cells(n, rows, r, world) for r in range(world)) == n * rows
-        if world > 1:
-            cells = [shard_cells(n, rows, r, world) for r in range(world)]
-            assert max(cells) < 1.25 * min(cells)
+        widths = [e - b for b, e in spans]
+        assert max(widths) - min(widths) <= 12288

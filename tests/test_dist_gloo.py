@@ -1,9 +1,10 @@
 """The N>1 path on CPU: world_size-2 (and 3) gloo groups run havac_amd.dist.gather_hits on shards.
 
 No GPU here, and the product has no CPU compute path, so each rank's shard of hits is produced by the
-CPU checker (test infrastructure) filtered to the diagonals havac_ssv_shard_diagonals assigns to that
-rank -- exactly the records the rank's GPU would report (tests/test_gpu_scale.py proves that on the GPU).
-What is under test is everything after the kernel: shard arithmetic, the two collectives, the merge."""
+CPU checker (test infrastructure) filtered to the columns havac_ssv_shard_columns assigns to that
+rank -- exactly the records the rank's GPU reports, in the same order (tests/test_gpu_scale.py proves
+that on the GPU).  What is under test is everything after the kernel: shard arithmetic, the two
+collectives, and that concatenation in rank order is already the reference's device order."""
 import os
 import socket
 import sys
@@ -33,35 +34,33 @@ def worker(rank, world, port, case, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from havac_amd import synth
     from havac_amd.dist import gather_hits
-    from havac_amd.ssv import shard_diagonals
+    from havac_amd.ssv import shard_columns
     from oracle import pyoracle as O
 
     if case == "empty":
         model = np.full((40, 4), -128, np.int8)
         sym = synth.random_symbols(synth.SEGMENT, 1)
-    elif case == "lopsided":               # all hits on diagonals of the last shard
+    elif case == "lopsided":               # all hits in the columns of the last shard
         model, cons = synth.dfam_like_model(300, 3)
         sym = synth.random_symbols(6 * synth.SEGMENT, 4)
         sym[: 5 * synth.SEGMENT] = 0
         model[:, 0] = -100
+        synth.plant_homologs(sym[5 * synth.SEGMENT:], cons, synth.SEGMENT, every=3000, length=280)
     else:
         model, cons = synth.model_collection([200, 900, 64], 11)
         sym = synth.random_symbols(12 * synth.SEGMENT, 12)
         synth.plant_homologs(sym, cons, sym.size, every=9000, length=500)
     whole = O.ssv(sym, model)
     rows, cols = O.unpack_hits(whole)
-    lo, hi = shard_diagonals(sym.size, model.shape[0], rank, world)
-    d = cols.astype(np.int64) - rows.astype(np.int64)
-    mine = whole[(d >= lo) & (d < hi)]
-    rng = np.random.default_rng(rank)
-    mine = mine[rng.permutation(mine.size)]                     # arrival order inside a shard is arbitrary
+    lo, hi = shard_columns(sym.size, rank, world)
+    mine = whole[(cols >= lo) & (cols < hi)]                      # a slice of the device-ordered whole
     cap = max(8, mine.size + 5)
     local = torch.zeros(cap, dtype=torch.int64)
     local[: mine.size] = torch.from_numpy(mine.view(np.int64))
     merged, counts = gather_hits(local, int(mine.size))
     assert counts[rank] == mine.size and sum(counts) == whole.size
     if rank == 0:
-        got = O.device_order(merged.numpy().view(np.uint64))     # rank 0's final ordering (GPU: havac_ssv_sort_hits)
+        got = merged.numpy().view(np.uint64)                     # no sort on rank 0: rank order is device order
         np.save(out_path, np.array([int(np.array_equal(got, whole)), whole.size, max(counts), min(counts)]))
     else:
         assert merged is None
