@@ -32,7 +32,7 @@ def gather_hits(local_hits: torch.Tensor, local_count: int, group=None):
     mine = torch.tensor([local_count], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts, mine, group=group)
-    counts = [int(c.item()) for c in counts]
+    counts = torch.cat(counts).tolist()          # one device-to-host sync for all ranks' counts
     biggest = max(counts)
     if biggest == 0:
         return (local_hits[:0].to(out_dev) if rank == 0 else None), counts
