@@ -104,3 +104,21 @@ def test_c3_many_models_windows(torch_dev, oracle):
     packed = synth.random_packed(n, 1303)
     got = run_shards(torch, dev, packed, model, capacity=1 << 23)[0]
     check_windows(oracle, packed, model, got, [(0, 1500), (n - 1500, n), (600_000, 601_500)])
+
+
+def test_sort_hits_entry_point(torch_dev, oracle):
+    """havac_ssv_sort_hits: any list of packed records -> the reference's device order, in place."""
+    torch, dev = torch_dev
+    from havac_amd.ssv import SsvContext
+    rng = np.random.default_rng(12)
+    n = 300_000
+    rows = rng.integers(0, 1 << 24, size=n, dtype=np.uint64)
+    cols = rng.integers(0, 1 << 32, size=n, dtype=np.uint64)
+    recs = oracle.pack_hits(rows, cols)
+    t = torch.from_numpy(recs.view(np.int64).copy()).to(dev)
+    ctx = SsvContext()
+    ctx.sort_hits(t.data_ptr(), n, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    got = t.cpu().numpy().view(np.uint64)
+    ctx.close()
+    assert np.array_equal(got, oracle.device_order(recs))
