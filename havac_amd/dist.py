@@ -28,7 +28,8 @@ def gather_hits(local_hits: torch.Tensor, local_count: int, group=None):
     out_dev = local_hits.device
     # gloo (CPU rehearsals and the tests) moves host tensors; nccl = RCCL moves device tensors over xGMI
     dev = torch.device("cpu") if dist.get_backend(group) == "gloo" else out_dev
-    local_hits = local_hits[:local_count].to(dev)
+    capacity = local_hits.numel()
+    local_hits = local_hits.to(dev) if dev != out_dev else local_hits
     mine = torch.tensor([local_count], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts, mine, group=group)
@@ -36,8 +37,9 @@ def gather_hits(local_hits: torch.Tensor, local_count: int, group=None):
     biggest = max(counts)
     if biggest == 0:
         return (local_hits[:0].to(out_dev) if rank == 0 else None), counts
-    padded = torch.zeros(biggest, dtype=local_hits.dtype, device=dev)
-    padded[:local_count] = local_hits[:local_count]
+    if biggest > capacity:
+        raise ValueError("ranks must use hit buffers of one capacity (a rank reported more records than fit here)")
+    padded = local_hits[:biggest]                  # no copy: records beyond local_count are ignored by rank 0
     parts = [torch.empty(biggest, dtype=local_hits.dtype, device=dev) for _ in range(world)] if rank == 0 else None
     dist.gather(padded, parts, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     if rank != 0:

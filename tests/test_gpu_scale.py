@@ -122,3 +122,44 @@ def test_sort_hits_entry_point(torch_dev, oracle):
     got = t.cpu().numpy().view(np.uint64)
     ctx.close()
     assert np.array_equal(got, oracle.device_order(recs))
+
+
+def test_columns_beyond_2_to_32(torch_dev, oracle):
+    """5.0e9 columns (1.25 GB packed): more than the reference's 32-bit symbol count allows
+    (host/HavacHwClient.cpp:81), inside the record format's 26-bit segment field.  Windows at both ends."""
+    torch, dev = torch_dev
+    nseg = 407_000                                              # 5,001,216,000 columns
+    n = nseg * synth.SEGMENT
+    assert n > (1 << 32)
+    packed = synth.random_packed(n, 4242)
+    model, cons = synth.dfam_like_model(96, 4243)
+    got = run_shards(torch, dev, packed, model, capacity=1 << 23)[0]
+    _, cols = oracle.unpack_hits(got)
+    assert got.size > 100_000 and int(cols.max()) > (1 << 32)
+    assert np.array_equal(got, oracle.device_order(got))
+    check_windows(oracle, packed, model, got, [(0, 200_000), (n - 200_000, n), ((1 << 32) - 100_000, (1 << 32) + 100_000)])
+
+
+def test_c4_shape_one_shard_of_eight(torch_dev, oracle):
+    """Config C4's sharding at reduced height: a 1 Gbp database, 3000 model rows, shard 5 of 8 (what rank 5 of an
+    8-GPU node computes); windows inside the shard, at its two edges (halo side and cut side), none outside."""
+    torch, dev = torch_dev
+    from havac_amd.ssv import SsvContext, shard_columns
+    n = 81_381 * synth.SEGMENT                                  # 1,000,009,728 columns
+    packed = synth.random_packed(n, 777)
+    model, cons = synth.model_collection([900, 1300, 800], 778)
+    lo, hi = shard_columns(n, 5, 8)
+    ctx = SsvContext()
+    d_seq = torch.from_numpy(packed).to(dev)
+    d_phmm = torch.from_numpy(model.reshape(-1)).to(dev)
+    cap = 1 << 24
+    hits = torch.empty(cap, dtype=torch.int64, device=dev)
+    ctx.enqueue(d_seq.data_ptr(), n, d_phmm.data_ptr(), model.shape[0], hits.data_ptr(), cap, 5, 8, 0,
+                torch.cuda.current_stream(dev).cuda_stream)
+    found = ctx.finish()
+    got = hits[:found].cpu().numpy().view(np.uint64).copy()
+    ctx.close()
+    _, cols = oracle.unpack_hits(got)
+    assert found > 1_000_000 and int(cols.min()) >= lo and int(cols.max()) < hi
+    assert np.array_equal(got, oracle.device_order(got))
+    check_windows(oracle, packed, model, got, [(lo, lo + 20_000), (hi - 20_000, hi), ((lo + hi) // 2 // 4 * 4, (lo + hi) // 2 // 4 * 4 + 20_000)])
