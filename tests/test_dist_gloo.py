@@ -54,7 +54,7 @@ def worker(rank, world, port, case, out_path):
     rows, cols = O.unpack_hits(whole)
     lo, hi = shard_columns(sym.size, rank, world)
     mine = whole[(cols >= lo) & (cols < hi)]                      # a slice of the device-ordered whole
-    cap = max(8, mine.size + 5)
+    cap = whole.size + 8                                        # one capacity on every rank, as in ShardedSsv
     local = torch.zeros(cap, dtype=torch.int64)
     local[: mine.size] = torch.from_numpy(mine.view(np.int64))
     merged, counts = gather_hits(local, int(mine.size))
