@@ -26,6 +26,7 @@ SIGNATURES = {
     "havac_dev_set_hit_capacity": (C.c_int, [_vp, C.c_uint64]),
     "havac_dev_write_sequence": (C.c_int, [_vp, _u8p, C.c_uint64]),
     "havac_dev_write_phmm": (C.c_int, [_vp, _i8p, C.c_uint64]),
+    "havac_dev_write_separator_mask": (C.c_int, [_vp, _u8p, C.c_uint64]),
     "havac_dev_run_async": (C.c_int, [_vp]),
     "havac_dev_state": (C.c_int, [_vp]),
     "havac_dev_wait": (C.c_int, [_vp, C.c_uint32]),
@@ -38,6 +39,7 @@ SIGNATURES = {
     "havac_ssv_ctx_destroy": (None, [_vp]),
     "havac_ssv_enqueue": (C.c_int, [_vp, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "havac_ssv_set_separator_mask": (C.c_int, [_vp, C.c_void_p]),
     "havac_ssv_finish": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "havac_ssv_sort_hits": (C.c_int, [_vp, C.c_void_p, C.c_uint64, C.c_void_p]),
     "havac_ssv_last_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

@@ -85,6 +85,7 @@ void shard_tiles(const Tiling& t, uint32_t nrows, uint64_t col_begin, uint64_t c
 struct havac_ssv_ctx {
     int device = 0;
     uint32_t* rows8 = nullptr; size_t rows8_rows = 0;   // padded copy of the model
+    const uint16_t* pair_mask = nullptr;                // optional separator bitmap (boundary mode), caller-owned
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     uint64_t* sort_alt = nullptr; size_t sort_alt_count = 0;
     unsigned long long* d_count = nullptr;
@@ -138,6 +139,13 @@ extern "C" uint64_t havac_ssv_shard_cells(uint64_t nsymbols, uint32_t nrows, uin
     uint64_t b, e;
     shard_columns(nsymbols, shard_index, shard_count, &b, &e);
     return (e - b) * (uint64_t)nrows;
+}
+
+extern "C" int havac_ssv_set_separator_mask(havac_ssv_ctx* c, const uint8_t* d_pair_mask) {
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (((uintptr_t)d_pair_mask & 1u)) { c->err = "separator mask must be 2-byte aligned"; return HAVAC_E_ARGUMENT; }
+    c->pair_mask = reinterpret_cast<const uint16_t*>(d_pair_mask);
+    return HAVAC_OK;
 }
 
 extern "C" int havac_ssv_shard_columns(uint64_t nsymbols, uint32_t shard_index, uint32_t shard_count,
@@ -204,7 +212,8 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         uint32_t nblocks = (te - tb + kWavesPerBlock - 1) / kWavesPerBlock;
         hipLaunchKernelGGL(ssv_diag_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream,
                            d_sequence, (int64_t)nsymbols, (const uint32_t*)c->rows8, t.nrows_padded, t.first_diag,
-                           tb, te, (int64_t)col_begin, (int64_t)col_end, d_hits, c->d_count, hit_capacity, d_abort_flag);
+                           tb, te, (int64_t)col_begin, (int64_t)col_end, d_hits, c->d_count, hit_capacity, d_abort_flag,
+                           c->pair_mask);
     }
     HIP_TRY(c->err, hipEventRecord(c->ev[2], stream));
     HIP_TRY(c->err, hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
@@ -292,6 +301,7 @@ struct havac_dev {
     havac_ssv_ctx* ctx = nullptr;
     uint8_t* d_seq = nullptr; uint64_t seq_bytes = 0; uint64_t seq_alloc = 0;
     int8_t* d_phmm = nullptr; uint64_t phmm_bytes = 0; uint64_t phmm_alloc = 0;
+    uint8_t* d_mask = nullptr; uint64_t mask_bytes = 0; uint64_t mask_alloc = 0;   // separator bitmap, optional
     uint64_t* d_hits = nullptr; uint64_t hit_capacity = 0;
     uint32_t* d_abort = nullptr;        // device word the kernel polls (cache-bypassing loads)
     hipStream_t abort_stream = nullptr; // abort() writes the word from here while the kernel runs
@@ -343,6 +353,7 @@ extern "C" void havac_dev_destroy(havac_dev* d) {
     if (d->ctx) havac_ssv_ctx_destroy(d->ctx);
     if (d->d_seq) (void)hipFree(d->d_seq);
     if (d->d_phmm) (void)hipFree(d->d_phmm);
+    if (d->d_mask) (void)hipFree(d->d_mask);
     if (d->d_hits) (void)hipFree(d->d_hits);
     if (d->d_abort) (void)hipFree(d->d_abort);
     if (d->abort_stream) (void)hipStreamDestroy(d->abort_stream);
@@ -388,8 +399,21 @@ extern "C" int havac_dev_write_sequence(havac_dev* d, const uint8_t* packed, uin
         return HAVAC_E_LENGTH;
     }
     d->seq_bytes = nbytes;
+    d->mask_bytes = 0;                       // a new sequence has no separators until a mask is written for it
     if (nbytes == 0) return HAVAC_OK;
     return upload(d, &d->d_seq, &d->seq_alloc, packed, nbytes);
+}
+
+extern "C" int havac_dev_write_separator_mask(havac_dev* d, const uint8_t* pair_bitmap, uint64_t nbytes) {
+    if (!d || (!pair_bitmap && nbytes)) return HAVAC_E_ARGUMENT;
+    if (nbytes == 0) { d->mask_bytes = 0; return HAVAC_OK; }
+    if (nbytes != d->seq_bytes / 4) {        // one bit per symbol pair = 1/8 bit per packed bit
+        d->err = "separator mask must hold one bit per symbol pair of the sequence written before it (" +
+                 std::to_string(d->seq_bytes / 4) + " bytes), got " + std::to_string(nbytes);
+        return HAVAC_E_LENGTH;
+    }
+    d->mask_bytes = nbytes;
+    return upload(d, &d->d_mask, &d->mask_alloc, pair_bitmap, nbytes);
 }
 
 extern "C" int havac_dev_write_phmm(havac_dev* d, const int8_t* scores, uint64_t nbytes) {
@@ -420,6 +444,7 @@ extern "C" int havac_dev_run_async(havac_dev* d) {
     HIP_TRY(d->err, hipMemsetAsync(d->d_abort, 0, sizeof(uint32_t), d->stream));
     d->abort_requested = false;
     d->aborted = false; d->failed = false; d->finished = false; d->found = 0;
+    havac_ssv_set_separator_mask(d->ctx, d->mask_bytes ? d->d_mask : nullptr);
     int rc = havac_ssv_enqueue(d->ctx, d->d_seq, d->seq_bytes * 4, d->d_phmm, (uint32_t)(d->phmm_bytes / 4), 0, 1,
                                d->d_hits, d->hit_capacity, d->d_abort, d->stream);
     if (rc) { d->err = havac_ssv_ctx_last_error(d->ctx); return rc; }

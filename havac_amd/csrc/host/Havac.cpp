@@ -1,6 +1,7 @@
 // Havac.cpp -- host/Havac.cpp:20-206 on top of the C ABI of libhavac_dev.so.
 #include "Havac.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <iostream>
 #include <new>
@@ -54,8 +55,9 @@ void Havac::loadPhmm(const std::string phmmSrc) {
     if (rc == p7HmmFileNotFound) throw std::runtime_error("Could not open phmm file for reading.");
     if (rc == p7HmmAllocationFailure) throw std::bad_alloc();
     if (rc == p7HmmFormatError) throw std::runtime_error("Phmm file was not formatted correctly.");
-    PhmmPreprocessor preprocessor(p7HmmList, requiredPValue);
+    PhmmPreprocessor preprocessor(p7HmmList, requiredPValue, boundaryMode_);
     compressedPhmmScores = preprocessor.getProcessedPhmmData();
+    modelStarts_ = preprocessor.getModelStarts();
     check(havac_dev_write_phmm(dev_, compressedPhmmScores->data(), compressedPhmmScores->size()));
     phmmLoadedToDevice = true;
 }
@@ -65,9 +67,15 @@ void Havac::loadSequence(const std::string fastaSrc) {
     if (rc == FASTA_VECTOR_ALLOCATION_FAIL) throw std::bad_alloc();
     if (rc == FASTA_VECTOR_FILE_OPEN_FAIL) throw std::runtime_error("Could not open fasta file for reading.");
     if (rc == FASTA_VECTOR_FILE_READ_FAIL) throw std::runtime_error("Error while reading from the opened fasta file.");
-    SequencePreprocessor preprocessor(fastaVector);
+    SequencePreprocessor preprocessor(fastaVector, boundaryMode_);
     vector<uint8_t> &packed = preprocessor.getCompressedSequenceBuffer();
     check(havac_dev_write_sequence(dev_, packed.data(), packed.size()));
+    if (boundaryMode_) {
+        vector<uint8_t> &mask = preprocessor.getSeparatorMask();
+        check(havac_dev_write_separator_mask(dev_, mask.data(), mask.size()));
+        recordStarts_ = preprocessor.getRecordStarts();
+        recordLengths_ = preprocessor.getRecordLengths();
+    }
     sequenceLoadedToDevice = true;
 }
 
@@ -92,6 +100,12 @@ enum havac_cmd_state Havac::currentHardwareState() {
     int s = havac_dev_state(dev_);
     check(s);
     return (havac_cmd_state)s;
+}
+
+void Havac::setBoundaryMode(bool on) {
+    if (phmmLoadedToDevice || sequenceLoadedToDevice)
+        throw std::logic_error("setBoundaryMode must be called before loadPhmm and loadSequence.");
+    boundaryMode_ = on;
 }
 
 void Havac::setHitCapacity(uint64_t maxHits) { check(havac_dev_set_hit_capacity(dev_, maxHits)); }
@@ -150,8 +164,25 @@ vector<HavacHit> Havac::getHitsFromFinishedRun() {
     check(havac_dev_num_hits(dev_, &n));
     rawHits_.assign(n, 0);
     if (n) check(havac_dev_read_hits(dev_, rawHits_.data(), n));
-    vector<uint32_t> sums = generatePhmmLenPrefixSums();
-    return havacResolveHits(rawHits_, fastaVector, sums);
+    if (!boundaryMode_) {
+        vector<uint32_t> sums = generatePhmmLenPrefixSums();
+        return havacResolveHits(rawHits_, fastaVector, sums);
+    }
+    // boundary mode: records and models have their own start tables (separators in between)
+    vector<HavacHit> out;
+    out.reserve(rawHits_.size());
+    for (uint64_t rec : rawHits_) {
+        const uint64_t column = ((rec >> 14) & 0x3ffffffull) * 12288ull + (rec & 0x3fffull);
+        const uint32_t row = (uint32_t)(rec >> 40);
+        size_t j = std::upper_bound(recordStarts_.begin(), recordStarts_.end(), column) - recordStarts_.begin();
+        size_t k = std::upper_bound(modelStarts_.begin(), modelStarts_.end(), row) - modelStarts_.begin();
+        if (j == 0 || k == 0) continue;
+        j--; k--;
+        if (column - recordStarts_[j] >= recordLengths_[j]) continue;                     // separator or padding column
+        if (row - modelStarts_[k] >= p7HmmList->phmms[k].header.modelLength) continue;    // separator row
+        out.push_back(HavacHit(column - recordStarts_[j], (uint32_t)j, row - modelStarts_[k], (uint32_t)k));
+    }
+    return out;
 }
 
 HavacHit::HavacHit(const uint64_t sequencePosition, const uint32_t sequenceIndex, const uint32_t phmmPosition,

@@ -66,6 +66,10 @@ public:
     enum havac_cmd_state currentHardwareState();
 
     // ---- additions (not in the reference) ----
+    // Boundary mode: every (model, record) pair is scored on its own, as the
+    // reference's second CPU SSV does (host/test/Ssv.cpp:8-68), instead of one diagonal sweep over the
+    // concatenation.  Call before loadPhmm / loadSequence.  Default off = the reference's device semantics.
+    void setBoundaryMode(bool on);
     void setHitCapacity(uint64_t maxHits);                 // the reference's buffer is a fixed 3.5 GiB
     void lastRunMilliseconds(float *ssvKernelMs, float *totalMs);
     const vector<uint64_t> &rawHitsOfLastFetch() const { return rawHits_; }
@@ -83,6 +87,9 @@ private:
     bool phmmLoadedToDevice = false;
     bool sequenceLoadedToDevice = false;
     vector<uint64_t> rawHits_;
+    bool boundaryMode_ = false;
+    vector<uint64_t> recordStarts_, recordLengths_;        // boundary mode: global column of each record
+    vector<uint32_t> modelStarts_;                         // boundary mode: global row of each model
 };
 
 // The resolver of host/Havac.cpp:145-187 as a free function (testable without a device):

@@ -14,6 +14,11 @@ public:
     // Projects every model for `desiredPvalue` and lays the tables back to back, no separator
     // (host/phmm/PhmmPreprocessor.cpp:9-31): diagonals run across model boundaries.
     PhmmPreprocessor(P7HmmList *phmmList, const float desiredPvalue = 0.05f);
+    // Boundary mode (not in the reference): two rows of -128 follow every model, so a
+    // diagonal cannot carry a score from one model into the next (255 - 128 - 128 < 0).  getModelStarts() gives the
+    // global row of each model's first position.
+    PhmmPreprocessor(P7HmmList *phmmList, const float desiredPvalue, bool boundaryMode);
+    const std::vector<uint32_t> &getModelStarts() const { return modelStarts_; }
     std::shared_ptr<std::vector<int8_t>> getProcessedPhmmData() { return data_; }
     uint32_t getPhmmLengthInBytes() const { return (uint32_t)data_->size(); }
     uint32_t getPhmmListLengthInVectors() const { return rows_; }
@@ -21,5 +26,6 @@ public:
 private:
     std::shared_ptr<std::vector<int8_t>> data_;
     uint32_t rows_ = 0;
+    std::vector<uint32_t> modelStarts_;
 };
 #endif

@@ -64,6 +64,42 @@ SequencePreprocessor::SequencePreprocessor(FastaVector *fastaVector) {
     for (; i < count; i++) slow(i);
 }
 
+SequencePreprocessor::SequencePreprocessor(FastaVector *fastaVector, bool boundaryMode) {
+    if (!boundaryMode) { *this = SequencePreprocessor(fastaVector); return; }
+    // layout pass: record j occupies [start_j, start_j + len_j), then padding to an even column, then 2 separators
+    uint64_t at = 0;
+    for (size_t j = 0; j < fastaVector->metadata.count; j++) {
+        const uint64_t begin = j ? fastaVector->metadata.data[j - 1].sequenceEndPosition : 0;
+        const uint64_t len = fastaVector->metadata.data[j].sequenceEndPosition - begin;     // terminator included
+        recordStarts_.push_back(at);
+        recordLengths_.push_back(len);
+        at += len;
+        at += at & 1;        // separator pairs sit on even columns
+        at += 2;
+    }
+    originalLength_ = (uint32_t)at;
+    segments_ = (uint32_t)((at + (kSegment - 1)) / kSegment);
+    symbols_ = segments_ * kSegment;
+    bytes_ = symbols_ / 4;
+    packed_.assign(bytes_, 0);
+    mask_.assign(symbols_ / 16, 0);
+    auto put = [&](uint64_t col, uint8_t code) { packed_[col / 4] |= (uint8_t)(code << ((col % 4) * 2)); };
+    const unsigned char *chars = reinterpret_cast<const unsigned char *>(fastaVector->sequence.charData);
+    for (size_t j = 0; j < recordStarts_.size(); j++) {
+        const uint64_t begin = j ? fastaVector->metadata.data[j - 1].sequenceEndPosition : 0;
+        for (uint64_t i = 0; i < recordLengths_[j]; i++) {
+            uint8_t code = kCodes.code[chars[begin + i]];
+            if (code > 2) code = 3;                                  // host/test/Ssv.cpp:29-34: default -> 3
+            put(recordStarts_[j] + i, code);
+        }
+        uint64_t sep = recordStarts_[j] + recordLengths_[j];
+        sep += sep & 1;
+        mask_[sep / 16] |= (uint8_t)(1u << ((sep / 2) % 8));
+    }
+    // the padding after the last record is masked too: nothing can hit there
+    for (uint64_t col = at; col < symbols_; col += 2) mask_[col / 16] |= (uint8_t)(1u << ((col / 2) % 8));
+}
+
 uint8_t SequencePreprocessor::getCompressedSymbol(const char c) {
     switch (c) {
         case 'a': case 'A': return 0;

@@ -13,6 +13,16 @@ public:
     // Packs every character of fastaVector->sequence (record terminators included) and pads
     // with zero bytes to a whole number of 12288-symbol segments.
     explicit SequencePreprocessor(struct FastaVector *fastaVector);
+    // Boundary mode (not in the reference): every record keeps its own columns -- its
+    // residues and its terminator column, as the reference counts them -- followed, at an even column, by one
+    // separator pair that the device scores -128 on every row, so no diagonal survives from one record into the
+    // next.  Characters other than a/c/g (terminator, N, ambiguity codes) are 'T', as in the reference's per-pair
+    // CPU SSV (host/test/Ssv.cpp:29-34); rand() is not used.
+    SequencePreprocessor(struct FastaVector *fastaVector, bool boundaryMode);
+    // boundary mode only: one bit per aligned symbol pair, set on separator pairs; global column of each record
+    std::vector<uint8_t> &getSeparatorMask() { return mask_; }
+    const std::vector<uint64_t> &getRecordStarts() const { return recordStarts_; }
+    const std::vector<uint64_t> &getRecordLengths() const { return recordLengths_; }   // terminator column included
     std::vector<uint8_t> &getCompressedSequenceBuffer() { return packed_; }
     uint32_t getCompressedSequenceLengthInSegments() const { return segments_; }
     uint32_t getCompressedSequenceLengthInSymbols() const { return symbols_; }
@@ -24,5 +34,7 @@ public:
 private:
     uint32_t originalLength_ = 0, segments_ = 0, symbols_ = 0, bytes_ = 0;
     std::vector<uint8_t> packed_;
+    std::vector<uint8_t> mask_;
+    std::vector<uint64_t> recordStarts_, recordLengths_;
 };
 #endif

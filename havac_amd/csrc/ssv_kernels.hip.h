@@ -31,10 +31,12 @@
 //    per step pair, indexed by the 4-bit code of the symbol pair, returns both
 //    steps' match words in one conflict-free ds_read_b64 (16 entries x 2 banks
 //    = 32 distinct banks).  The wave rebuilds its 16 tables (2.2 KB) once per
-//    32-step chunk with 8 v_perm_b32 per lane.  A 17th entry per table scores
-//    -1 for "outside the matrix" (columns < 0 or >= N), which pins a cell at 0
-//    and can never hit: the hot loop has no per-cell predicate and no separate
-//    edge path.  What remains on the VALU per register and step pair is two
+//    32-step chunk with 5 v_perm_b32 per lane.  A 17th entry per table scores
+//    -128 for "outside the matrix" (columns < 0 or >= N), which pins a cell at
+//    0 and can never hit: the hot loop has no per-cell predicate and no separate
+//    edge path.  The same entry serves the optional separator mask (boundary
+//    mode): a masked symbol pair takes 256 off every diagonal that crosses it,
+//    i.e. resets it.  What remains on the VALU per register and step pair is two
 //    v_pk_add_i16 and half a v_or3_b32.
 //  * The symbol window slides one position per step; the 32 step-pair codes a
 //    lane needs per chunk are addresses (code*8 + table base) held in VGPRs and
@@ -65,7 +67,7 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kModelSlack = 40;                   // padding rows kept behind the padded model (table look-ahead)
 constexpr uint32_t kScoreZero = 0x80008000u;      // two cells at score 0: 256*0 - 32768
 constexpr uint32_t kCrossedBits = 0x00010001u;    // bit 0 of either cell: set only in 0x7fff-derived values
-constexpr uint32_t kOutsideWord = 0xff00ff00u;    // match word "score -1" for both cells
+constexpr uint32_t kOutsideWord = 0x80008000u;    // match word "score -128" for both cells
 constexpr uint32_t kPadRow = 0x80808080u;         // a row outside the model: -128 for every symbol
 
 // per-wave LDS: 16 step-pair tables of 17 entries x 8 B, the parked hit masks of half a chunk, the record stage
@@ -293,7 +295,8 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
                      const uint32_t nrows_padded, const int64_t first_diag, const uint32_t tile_begin,
                      const uint32_t tile_end, const int64_t col_begin, const int64_t col_end,
                      uint64_t* __restrict__ hits, unsigned long long* __restrict__ hit_count,
-                     const uint64_t hit_capacity, const uint32_t* __restrict__ abort_flag) {
+                     const uint64_t hit_capacity, const uint32_t* __restrict__ abort_flag,
+                     const uint16_t* __restrict__ pair_mask) {
     __shared__ WaveLds wave_lds[kWavesPerBlock];
 
     const int lane = threadIdx.x & 63;
@@ -331,11 +334,17 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
     // table entry of the symbol pair (j+2k, j+2k+1).  The upper half of one chunk's window is the lower half of the
     // next, so each chunk expands only the 32 new symbols.
     uint32_t C[32];
-    auto fetch_symbols = [&](int64_t rel) -> uint2 {     // symbols [dl+rel, dl+rel+32); rel is wave-uniform
+    // packed symbols [dl+rel, dl+rel+32) in x,y; in z the 16 separator bits of those symbol pairs (boundary mode);
+    // rel is wave-uniform
+    auto fetch_symbols = [&](int64_t rel) -> uint3 {
         const bool edge = (d0 + rel < 0) || (d0 + rel + kTileDiags > nsymbols);   // the wave's 2048 positions
-        return load_symbols(seq, nsymbols, dl + rel, edge);
+        const int64_t pos = dl + rel;
+        const uint2 w = load_symbols(seq, nsymbols, pos, edge);
+        uint32_t separators = 0;
+        if (pair_mask && pos >= 0 && pos + 32 <= nsymbols) separators = pair_mask[pos >> 5];
+        return make_uint3(w.x, w.y, separators);
     };
-    auto expand = [&](const uint2 packed, int64_t rel) {  // -> C[16 .. 32)
+    auto expand = [&](const uint3 packed, int64_t rel) {  // -> C[16 .. 32)
         const bool edge = (d0 + rel < 0) || (d0 + rel + kTileDiags > nsymbols);
         const int64_t pos = dl + rel;
 #pragma unroll
@@ -352,6 +361,12 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
                 const int64_t q = pos + 2 * k;     // q and q+1 are in or out together (pos, N even)
                 if (q < 0 || q >= nsymbols) C[16 + k] = table_base + kOutsideCode;
             }
+        }
+        if (pair_mask && __any(packed.z != 0)) {
+            // boundary mode: a separator pair scores -128 twice on every diagonal through it = a reset
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if ((packed.z >> k) & 1u) C[16 + k] = table_base + kOutsideCode;
         }
     };
     // A chunk's 16 step-pair tables: entry (a,b) of pair P = { word(step 2P, a), word(step 2P+1, b) } with
@@ -371,7 +386,7 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
     expand(fetch_symbols(p_lo), p_lo);
     // the global loads of a chunk are issued one chunk ahead, so their latency hides behind 16 step pairs
     ModelRows next_rows = fetch_rows(p_lo);
-    uint2 next_symbols = fetch_symbols(p_lo + 32);
+    uint3 next_symbols = fetch_symbols(p_lo + 32);
 
     for (int64_t p0 = p_lo; p0 < p_hi; p0 += kChunkRows) {
         // abort: a device word, read past the caches every 2048 rows (never on a wave's first chunk, so

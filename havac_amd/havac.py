@@ -31,6 +31,7 @@ HOST_SIGNATURES = {
     "havac_host_abort": (C.c_int, [_vp]),
     "havac_host_state": (C.c_int, [_vp]),
     "havac_host_set_hit_capacity": (C.c_int, [_vp, C.c_uint64]),
+    "havac_host_set_boundary_mode": (C.c_int, [_vp, C.c_int]),
     "havac_host_get_hits": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "havac_host_get_raw_hits": (C.c_int, [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "havac_host_last_run_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -120,6 +121,10 @@ class Havac:
 
     def currentHardwareState(self) -> int:
         return self._check(self._L.havac_host_state(self._h))
+
+    def setBoundaryMode(self, on: bool):
+        """Not in the reference: score every (model, record) pair on its own (host/test/Ssv.cpp semantics)."""
+        self._check(self._L.havac_host_set_boundary_mode(self._h, int(bool(on))))
 
     def setHitCapacity(self, n: int):
         self._check(self._L.havac_host_set_hit_capacity(self._h, n))

@@ -80,6 +80,11 @@ class HavacHwClient:
         buf = np.ascontiguousarray(compressedSequence, dtype=np.uint8)
         self._check(self._L.havac_dev_write_sequence(self._h, buf.ctypes.data, buf.size))
 
+    def writeSeparatorMask(self, pairBitmap):
+        """Boundary mode (not in the reference): one bit per aligned symbol pair; None or empty removes the mask."""
+        buf = np.ascontiguousarray(pairBitmap if pairBitmap is not None else [], dtype=np.uint8)
+        self._check(self._L.havac_dev_write_separator_mask(self._h, buf.ctypes.data if buf.size else None, buf.size))
+
     def writePhmm(self, phmmAsFlattenedArray):
         buf = np.ascontiguousarray(phmmAsFlattenedArray, dtype=np.int8).reshape(-1)
         self._check(self._L.havac_dev_write_phmm(self._h, buf.ctypes.data, buf.size))

@@ -98,6 +98,13 @@ int havac_dev_set_hit_capacity(havac_dev *dev, uint64_t max_hits);
  * Borrowed host pointer, copied to HBM before return. */
 int havac_dev_write_sequence(havac_dev *dev, const uint8_t *packed2bit, uint64_t nbytes);
 
+/* Optional, not in the reference ("boundary mode").  One bit per aligned symbol
+ * pair (bit k of byte j = symbols 16j+2k, 16j+2k+1) of the sequence written before it; a set bit makes both
+ * symbols score -128 on every model row, which resets every diagonal that crosses the pair (255-128-128 < 0)
+ * and can never hit.  Used by the host layer to separate FASTA records.  nbytes must be sequence bytes / 4;
+ * nbytes == 0 removes the mask.  Writing a new sequence removes it too. */
+int havac_dev_write_separator_mask(havac_dev *dev, const uint8_t *pair_bitmap, uint64_t nbytes);
+
 /* HavacHwClient::writePhmm  host/HavacHwClient.cpp:111-138. */
 int havac_dev_write_phmm(havac_dev *dev, const int8_t *scores, uint64_t nbytes);
 
@@ -167,6 +174,10 @@ int havac_ssv_enqueue(havac_ssv_ctx *ctx, const uint8_t *d_sequence, uint64_t ns
                       const int8_t *d_phmm, uint32_t nrows, uint32_t shard_index,
                       uint32_t shard_count, uint64_t *d_hits, uint64_t hit_capacity,
                       const uint32_t *d_abort_flag, void *hip_stream);
+
+/* Separator bitmap for the next passes (see havac_dev_write_separator_mask); a DEVICE pointer the caller keeps
+ * alive, 2-byte aligned, nsymbols/16 bytes; NULL (the default) = none. */
+int havac_ssv_set_separator_mask(havac_ssv_ctx *ctx, const uint8_t *d_pair_bitmap);
 
 /* Completes the enqueued pass: waits for it, puts the shard's records in
  * d_hits into device order (radix sort on the same stream) and returns the

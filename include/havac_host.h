@@ -30,6 +30,8 @@ int havac_host_wait(havac_host *h);                                    /* waitHa
 int havac_host_abort(havac_host *h);                                   /* abortHardwareClient  :100-102 */
 int havac_host_state(havac_host *h);                                   /* currentHardwareState :190-192 */
 int havac_host_set_hit_capacity(havac_host *h, uint64_t max_hits);
+/* Havac::setBoundaryMode (not in the reference): score every (model, record) pair on its own; before the loads */
+int havac_host_set_boundary_mode(havac_host *h, int on);
 /* Havac::getHitsFromFinishedRun :145-187.  First call with cap = 0 to learn the count. */
 int havac_host_get_hits(havac_host *h, uint64_t *sequence_position, uint32_t *sequence_index,
                         uint32_t *phmm_position, uint32_t *phmm_index, uint32_t cap, uint32_t *count);
