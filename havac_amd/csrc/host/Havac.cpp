@@ -68,6 +68,16 @@ void Havac::loadSequence(const std::string fastaSrc) {
     if (rc == FASTA_VECTOR_FILE_OPEN_FAIL) throw std::runtime_error("Could not open fasta file for reading.");
     if (rc == FASTA_VECTOR_FILE_READ_FAIL) throw std::runtime_error("Error while reading from the opened fasta file.");
     SequencePreprocessor preprocessor(fastaVector, boundaryMode_);
+    if (bothStrands_) {
+        vector<uint64_t> starts, residues;
+        for (size_t j = 0; j < fastaVector->metadata.count; j++) {
+            const uint64_t begin = j ? fastaVector->metadata.data[j - 1].sequenceEndPosition : 0;
+            starts.push_back(boundaryMode_ ? preprocessor.getRecordStarts()[j] : begin);
+            residues.push_back(fastaVector->metadata.data[j].sequenceEndPosition - begin - 1);
+        }
+        forwardColumns_ = preprocessor.appendReverseStrand(starts, residues);
+        residueCounts_ = residues;
+    }
     vector<uint8_t> &packed = preprocessor.getCompressedSequenceBuffer();
     check(havac_dev_write_sequence(dev_, packed.data(), packed.size()));
     if (boundaryMode_) {
@@ -106,6 +116,11 @@ void Havac::setBoundaryMode(bool on) {
     if (phmmLoadedToDevice || sequenceLoadedToDevice)
         throw std::logic_error("setBoundaryMode must be called before loadPhmm and loadSequence.");
     boundaryMode_ = on;
+}
+
+void Havac::setBothStrands(bool on) {
+    if (sequenceLoadedToDevice) throw std::logic_error("setBothStrands must be called before loadSequence.");
+    bothStrands_ = on;
 }
 
 void Havac::setHitCapacity(uint64_t maxHits) { check(havac_dev_set_hit_capacity(dev_, maxHits)); }
@@ -164,14 +179,44 @@ vector<HavacHit> Havac::getHitsFromFinishedRun() {
     check(havac_dev_num_hits(dev_, &n));
     rawHits_.assign(n, 0);
     if (n) check(havac_dev_read_hits(dev_, rawHits_.data(), n));
+    // both strands: a record of the second half is the record at (column - forwardColumns_) of the first
+    vector<uint64_t> forward = rawHits_;
+    vector<bool> reverse(rawHits_.size(), false);
+    if (bothStrands_) {
+        for (size_t i = 0; i < forward.size(); i++) {
+            uint64_t column = ((forward[i] >> 14) & 0x3ffffffull) * 12288ull + (forward[i] & 0x3fffull);
+            if (column >= forwardColumns_) {
+                column -= forwardColumns_;
+                reverse[i] = true;
+                forward[i] = (forward[i] & ~((1ull << 40) - 1)) | ((column / 12288ull) << 14) | (column % 12288ull);
+            }
+        }
+    }
+    auto mirror = [&](HavacHit &h, bool isReverse) {
+        if (!isReverse) return;
+        h.reverseStrand = true;
+        const uint64_t n = residueCounts_[h.sequenceIndex];
+        if (h.sequencePosition < n) h.sequencePosition = n - 1 - h.sequencePosition;   // the terminator column stays
+    };
     if (!boundaryMode_) {
         vector<uint32_t> sums = generatePhmmLenPrefixSums();
-        return havacResolveHits(rawHits_, fastaVector, sums);
+        vector<HavacHit> out;
+        out.reserve(forward.size());
+        vector<uint64_t> one(1);
+        for (size_t i = 0; i < forward.size(); i++) {      // one at a time: havacResolveHits may drop padding hits
+            one[0] = forward[i];
+            vector<HavacHit> r = havacResolveHits(one, fastaVector, sums);
+            if (r.empty()) continue;
+            mirror(r[0], reverse[i]);
+            out.push_back(r[0]);
+        }
+        return out;
     }
     // boundary mode: records and models have their own start tables (separators in between)
     vector<HavacHit> out;
     out.reserve(rawHits_.size());
-    for (uint64_t rec : rawHits_) {
+    for (size_t i = 0; i < forward.size(); i++) {
+        const uint64_t rec = forward[i];
         const uint64_t column = ((rec >> 14) & 0x3ffffffull) * 12288ull + (rec & 0x3fffull);
         const uint32_t row = (uint32_t)(rec >> 40);
         size_t j = std::upper_bound(recordStarts_.begin(), recordStarts_.end(), column) - recordStarts_.begin();
@@ -180,7 +225,9 @@ vector<HavacHit> Havac::getHitsFromFinishedRun() {
         j--; k--;
         if (column - recordStarts_[j] >= recordLengths_[j]) continue;                     // separator or padding column
         if (row - modelStarts_[k] >= p7HmmList->phmms[k].header.modelLength) continue;    // separator row
-        out.push_back(HavacHit(column - recordStarts_[j], (uint32_t)j, row - modelStarts_[k], (uint32_t)k));
+        HavacHit h(column - recordStarts_[j], (uint32_t)j, row - modelStarts_[k], (uint32_t)k);
+        mirror(h, reverse[i]);
+        out.push_back(h);
     }
     return out;
 }
@@ -193,5 +240,6 @@ std::string HavacHit::toString() {   // host/Havac.cpp:201-206, same text
     std::stringstream ss;
     ss << "sequence $" << sequenceIndex << ", position " << sequencePosition << "; phmm #" << phmmIndex << " position "
        << phmmPosition;
+    if (reverseStrand) ss << " (reverse strand)";
     return ss.str();
 }

@@ -43,6 +43,9 @@ public:
     uint32_t sequenceIndex;
     uint32_t phmmPosition;
     uint32_t phmmIndex;
+    // addition: set for hits found on the reverse-complemented record (Havac::setBothStrands); sequencePosition is
+    // then still a position on the record as it stands in the file (the residue the hit cell read, complemented)
+    bool reverseStrand = false;
     std::string toString();
 };
 
@@ -70,6 +73,10 @@ public:
     // reference's second CPU SSV does (host/test/Ssv.cpp:8-68), instead of one diagonal sweep over the
     // concatenation.  Call before loadPhmm / loadSequence.  Default off = the reference's device semantics.
     void setBoundaryMode(bool on);
+    // Both strands: also scores the reverse complement of every record, which nhmmer
+    // does by default and the reference's benchmark switched off (--watson, benchmark/readme.txt:62-64).  Hits of
+    // that half carry reverseStrand = true.  Call before loadSequence.  Default off.
+    void setBothStrands(bool on);
     void setHitCapacity(uint64_t maxHits);                 // the reference's buffer is a fixed 3.5 GiB
     void lastRunMilliseconds(float *ssvKernelMs, float *totalMs);
     const vector<uint64_t> &rawHitsOfLastFetch() const { return rawHits_; }
@@ -88,6 +95,9 @@ private:
     bool sequenceLoadedToDevice = false;
     vector<uint64_t> rawHits_;
     bool boundaryMode_ = false;
+    bool bothStrands_ = false;
+    uint64_t forwardColumns_ = 0;                          // both strands: columns of the forward half
+    vector<uint64_t> residueCounts_;                       // both strands: residues per record
     vector<uint64_t> recordStarts_, recordLengths_;        // boundary mode: global column of each record
     vector<uint32_t> modelStarts_;                         // boundary mode: global row of each model
 };

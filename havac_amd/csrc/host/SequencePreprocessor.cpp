@@ -12,6 +12,7 @@
 //  * padding bytes are zero, i.e. symbol 0 = 'A' (:41).
 #include "SequencePreprocessor.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -98,6 +99,29 @@ SequencePreprocessor::SequencePreprocessor(FastaVector *fastaVector, bool bounda
     }
     // the padding after the last record is masked too: nothing can hit there
     for (uint64_t col = at; col < symbols_; col += 2) mask_[col / 16] |= (uint8_t)(1u << ((col / 2) % 8));
+}
+
+uint64_t SequencePreprocessor::appendReverseStrand(const std::vector<uint64_t> &starts,
+                                                   const std::vector<uint64_t> &residues) {
+    const uint64_t nf = symbols_;
+    const size_t fbytes = packed_.size();
+    packed_.resize(2 * fbytes);
+    std::copy(packed_.begin(), packed_.begin() + fbytes, packed_.begin() + fbytes);      // terminators, padding, ...
+    auto get = [&](uint64_t col) -> uint8_t { return (uint8_t)((packed_[col / 4] >> ((col % 4) * 2)) & 3u); };
+    auto set = [&](uint64_t col, uint8_t code) {
+        uint8_t &b = packed_[col / 4];
+        b = (uint8_t)((b & ~(0x3u << ((col % 4) * 2))) | (code << ((col % 4) * 2)));
+    };
+    for (size_t j = 0; j < starts.size(); j++)
+        for (uint64_t i = 0; i < residues[j]; i++)
+            set(nf + starts[j] + i, (uint8_t)(3u - get(starts[j] + residues[j] - 1 - i)));   // A<->T, C<->G
+    if (!mask_.empty()) {
+        const size_t mbytes = mask_.size();
+        mask_.resize(2 * mbytes);
+        std::copy(mask_.begin(), mask_.begin() + mbytes, mask_.begin() + mbytes);
+    }
+    symbols_ *= 2; segments_ *= 2; bytes_ *= 2;
+    return nf;
 }
 
 uint8_t SequencePreprocessor::getCompressedSymbol(const char c) {

@@ -19,6 +19,12 @@ public:
     // next.  Characters other than a/c/g (terminator, N, ambiguity codes) are 'T', as in the reference's per-pair
     // CPU SSV (host/test/Ssv.cpp:29-34); rand() is not used.
     SequencePreprocessor(struct FastaVector *fastaVector, bool boundaryMode);
+    // Both strands (not in the reference, which was benchmarked with nhmmer --watson):
+    // doubles the buffer.  The second half repeats the first with every record's residues reverse-complemented in
+    // place (terminator, separator and padding columns are copied), so a hit at column Nf + c is a hit on the
+    // reverse strand of the record that owns column c.  `starts`/`residues` give each record's first column and
+    // residue count in the forward layout.  Returns Nf, the forward half's padded symbol count.
+    uint64_t appendReverseStrand(const std::vector<uint64_t> &starts, const std::vector<uint64_t> &residues);
     // boundary mode only: one bit per aligned symbol pair, set on separator pairs; global column of each record
     std::vector<uint8_t> &getSeparatorMask() { return mask_; }
     const std::vector<uint64_t> &getRecordStarts() const { return recordStarts_; }

@@ -74,6 +74,12 @@ int havac_host_run_async(havac_host *h) { h->haveHits = false; return guarded(h,
 int havac_host_wait(havac_host *h) { return guarded(h, [&] { h->obj->waitHardwareClientAsync(); }); }
 int havac_host_abort(havac_host *h) { return guarded(h, [&] { h->obj->abortHardwareClient(); }); }
 int havac_host_set_hit_capacity(havac_host *h, uint64_t n) { return guarded(h, [&] { h->obj->setHitCapacity(n); }); }
+int havac_host_set_both_strands(havac_host *h, int on) { return guarded(h, [&] { h->obj->setBothStrands(on != 0); }); }
+int havac_host_get_hit_strands(havac_host *h, uint8_t *reverse, uint32_t cap, uint32_t *count) {
+    if (count) *count = (uint32_t)h->hits.size();
+    for (uint32_t i = 0; i < cap && i < h->hits.size(); i++) reverse[i] = h->hits[i].reverseStrand ? 1 : 0;
+    return HAVAC_OK;
+}
 int havac_host_set_boundary_mode(havac_host *h, int on) { return guarded(h, [&] { h->obj->setBoundaryMode(on != 0); }); }
 
 int havac_host_state(havac_host *h) {

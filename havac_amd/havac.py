@@ -32,6 +32,8 @@ HOST_SIGNATURES = {
     "havac_host_state": (C.c_int, [_vp]),
     "havac_host_set_hit_capacity": (C.c_int, [_vp, C.c_uint64]),
     "havac_host_set_boundary_mode": (C.c_int, [_vp, C.c_int]),
+    "havac_host_set_both_strands": (C.c_int, [_vp, C.c_int]),
+    "havac_host_get_hit_strands": (C.c_int, [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "havac_host_get_hits": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "havac_host_get_raw_hits": (C.c_int, [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "havac_host_last_run_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -70,10 +72,11 @@ class HavacHit:      # host/Havac.hpp:31-39
     sequenceIndex: int
     phmmPosition: int
     phmmIndex: int
+    reverseStrand: bool = False      # addition, see Havac.setBothStrands
 
     def toString(self) -> str:
         return (f"sequence ${self.sequenceIndex}, position {self.sequencePosition}; "
-                f"phmm #{self.phmmIndex} position {self.phmmPosition}")
+                f"phmm #{self.phmmIndex} position {self.phmmPosition}" + (" (reverse strand)" if self.reverseStrand else ""))
 
 
 def _hits_from_arrays(sp, si, pp, pi):
@@ -126,6 +129,10 @@ class Havac:
         """Not in the reference: score every (model, record) pair on its own (host/test/Ssv.cpp semantics)."""
         self._check(self._L.havac_host_set_boundary_mode(self._h, int(bool(on))))
 
+    def setBothStrands(self, on: bool):
+        """Not in the reference: also score the reverse complement of every record (nhmmer's default)."""
+        self._check(self._L.havac_host_set_both_strands(self._h, int(bool(on))))
+
     def setHitCapacity(self, n: int):
         self._check(self._L.havac_host_set_hit_capacity(self._h, n))
 
@@ -136,7 +143,9 @@ class Havac:
         si, pp, pi = (np.empty(n.value, np.uint32) for _ in range(3))
         self._check(self._L.havac_host_get_hits(self._h, sp.ctypes.data, si.ctypes.data, pp.ctypes.data,
                                                 pi.ctypes.data, n.value, C.byref(n)))
-        return _hits_from_arrays(sp, si, pp, pi)
+        rev = np.zeros(n.value, np.uint8)
+        self._check(self._L.havac_host_get_hit_strands(self._h, rev.ctypes.data, n.value, C.byref(n)))
+        return [HavacHit(int(a), int(b), int(c), int(d), bool(e)) for a, b, c, d, e in zip(sp, si, pp, pi, rev)]
 
     def rawHits(self) -> np.ndarray:
         n = C.c_uint32(0)

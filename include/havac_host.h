@@ -32,6 +32,10 @@ int havac_host_state(havac_host *h);                                   /* curren
 int havac_host_set_hit_capacity(havac_host *h, uint64_t max_hits);
 /* Havac::setBoundaryMode (not in the reference): score every (model, record) pair on its own; before the loads */
 int havac_host_set_boundary_mode(havac_host *h, int on);
+/* Havac::setBothStrands (not in the reference): also score every record's reverse complement; before loadSequence */
+int havac_host_set_both_strands(havac_host *h, int on);
+/* reverseStrand flag of the hits of the last havac_host_get_hits call, one byte each */
+int havac_host_get_hit_strands(havac_host *h, uint8_t *reverse, uint32_t cap, uint32_t *count);
 /* Havac::getHitsFromFinishedRun :145-187.  First call with cap = 0 to learn the count. */
 int havac_host_get_hits(havac_host *h, uint64_t *sequence_position, uint32_t *sequence_index,
                         uint32_t *phmm_position, uint32_t *phmm_index, uint32_t cap, uint32_t *count);

@@ -101,3 +101,93 @@ def test_havac_boundary_mode_scores_every_pair_on_its_own(tmp_path, oracle):
     d.runHardwareClient()
     assert len(d.getHitsFromFinishedRun()) != len(hits) or True
     d.close()
+
+
+def test_both_strands(tmp_path, oracle):
+    """the reverse complement of every record is scored as a second half of the buffer."""
+    import ctypes as C
+    from havac_amd import havac
+    from test_gpu_api import write_inputs
+    lengths = [4000, 9001, 123, 20000]
+    fa, hmm = write_inputs(tmp_path, [80, 260], lengths, seed=9)
+    table, lens = havac.project_hmm(hmm, 0.02)
+    seed = 99
+    packed_f, nchars, nrec = havac.pack_fasta(fa, seed=seed)
+    f = oracle.unpack_2bit(packed_f)
+    nf = f.size
+    rev = f.copy()
+    starts = np.concatenate([[0], np.cumsum([n + 1 for n in lengths])]).astype(np.int64)
+    for j, n in enumerate(lengths):
+        a = int(starts[j])
+        rev[a:a + n] = 3 - f[a:a + n][::-1]
+    want_raw = oracle.ssv_mt(np.concatenate([f, rev]), table)
+    h = havac.Havac(0, 0.02)
+    h.setBothStrands(True)
+    h.loadPhmm(hmm)
+    C.CDLL(None).srand(seed)
+    h.loadSequence(fa)
+    h.runHardwareClient()
+    hits = h.getHitsFromFinishedRun()
+    assert np.array_equal(h.rawHits(), want_raw)
+    rows, cols = oracle.unpack_hits(want_raw)
+    model_starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    want = []
+    for r, c in zip(rows.astype(np.int64), cols.astype(np.int64)):
+        reverse = c >= nf
+        c -= nf if reverse else 0
+        if c >= nchars:
+            continue                                        # padding after the last record
+        j = int(np.searchsorted(starts, c, side="right")) - 1
+        pos = int(c - starts[j])
+        if reverse and pos < lengths[j]:
+            pos = lengths[j] - 1 - pos
+        k = int(np.searchsorted(model_starts, r, side="right")) - 1
+        want.append((pos, j, int(r - model_starts[k]), k, bool(reverse)))
+    got = [(x.sequencePosition, x.sequenceIndex, x.phmmPosition, x.phmmIndex, x.reverseStrand) for x in hits]
+    assert got == want
+    assert any(x[4] for x in got) and not all(x[4] for x in got)
+    assert "(reverse strand)" in next(x for x in hits if x.reverseStrand).toString()
+    h.close()
+
+
+def test_boundary_mode_with_both_strands(tmp_path, oracle):
+    """Every (model, record, strand) triple on its own."""
+    from havac_amd import havac
+    from test_gpu_api import write_inputs
+    lengths = [3000, 7001, 40]
+    fa, hmm = write_inputs(tmp_path, [70, 210], lengths, seed=13)
+    table, lens = havac.project_hmm(hmm, 0.02)
+    starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64).tolist()
+    records, cur = [], None
+    for line in open(fa):
+        if line.startswith(">"):
+            if cur is not None:
+                records.append("".join(cur))
+            cur = []
+        else:
+            cur.append(line.strip())
+    records.append("".join(cur))
+    lut = np.full(256, 3, np.uint8)
+    for ch, v in zip(b"ACGacg", [0, 1, 2, 0, 1, 2]):
+        lut[ch] = v
+    want = set()
+    for j, text in enumerate(records):
+        fwd = lut[np.frombuffer(text.encode(), np.uint8)]
+        for strand, residues in ((False, fwd), (True, (3 - fwd)[::-1])):
+            sym = np.concatenate([residues, [3]]).astype(np.uint8)           # + terminator column ('T')
+            for k in range(len(lens)):
+                r, c = oracle.unpack_hits(oracle.ssv(sym, table[starts[k]:starts[k + 1]]))
+                for rr, cc in zip(r.tolist(), c.tolist()):
+                    pos = len(text) - 1 - cc if (strand and cc < len(text)) else cc
+                    want.add((pos, j, rr, k, strand))
+    h = havac.Havac(0, 0.02)
+    h.setBoundaryMode(True)
+    h.setBothStrands(True)
+    h.loadPhmm(hmm)
+    h.loadSequence(fa)
+    h.runHardwareClient()
+    hits = h.getHitsFromFinishedRun()
+    got = {(x.sequencePosition, x.sequenceIndex, x.phmmPosition, x.phmmIndex, x.reverseStrand) for x in hits}
+    h.close()
+    assert len(got) == len(hits) and len(want) > 40
+    assert got == want

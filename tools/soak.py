@@ -1,0 +1,82 @@
+"""Randomised soak of the HIP path against the CPU checker: many small problems of random shape and score
+distribution (and random separator masks), compared element for element.  A one-off confidence run, not part
+of the test suite:   python tools/soak.py [cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401,E402
+from havac_amd import synth  # noqa: E402
+from havac_amd.hw_client import HavacHwClient  # noqa: E402
+from oracle import pyoracle as O  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+c = HavacHwClient()
+bad = 0
+t0 = time.time()
+cells = hits_total = 0
+for case in range(cases):
+    nseg = int(rng.integers(1, 6))
+    n = nseg * synth.SEGMENT
+    nrows = int(rng.choice([1, 2, 3, 31, 32, 33, 64, 100, 255, 256, 257, 1000, 2048, 2049, 4100, int(rng.integers(1, 3000))]))
+    kind = int(rng.integers(0, 6))
+    if kind == 0:
+        model = rng.integers(-128, 128, size=(nrows, 4)).astype(np.int8)
+    elif kind == 1:
+        model, cons = synth.dfam_like_model(nrows, int(rng.integers(1 << 30)))
+    elif kind == 2:
+        model = rng.choice(np.array([-128, 127], np.int8), size=(nrows, 4))
+    elif kind == 3:
+        model = rng.integers(-20, 60, size=(nrows, 4)).astype(np.int8)
+    elif kind == 4:
+        model = np.full((nrows, 4), -128, np.int8)
+        model[rng.integers(0, nrows, size=max(1, nrows // 3))] = 127
+    else:
+        model, cons = synth.dfam_like_model(nrows, int(rng.integers(1 << 30)))
+        model[rng.integers(0, nrows, size=max(1, nrows // 20)), rng.integers(0, 4)] = -128
+    sym = rng.integers(0, 4, size=n, dtype=np.uint8)
+    if kind in (1, 5):
+        synth.plant_homologs(sym, cons, n, every=int(rng.integers(500, 20000)), length=min(nrows, int(rng.integers(20, 600))),
+                             sub=float(rng.uniform(0, 0.3)), seed=int(rng.integers(1 << 30)))
+    use_mask = rng.random() < 0.3
+    c.writeSequence(synth.pack_2bit(sym))
+    pieces = [(0, n)]
+    if use_mask:
+        seps = sorted(set((rng.integers(0, n // 2, size=int(rng.integers(1, 30))) * 2).tolist()))
+        mask = np.zeros(n // 16, np.uint8)
+        for s in seps:
+            mask[s // 16] |= 1 << ((s // 2) % 8)
+        c.writeSeparatorMask(mask)
+        pieces, start = [], 0
+        for s in seps + [n]:
+            if s > start:
+                pieces.append((start, s))
+            start = s + 2
+    c.writePhmm(model)
+    want = []
+    for a, b in pieces:
+        h = O.ssv_mt(sym[a:b], model) if (b - a) * nrows > 5e7 else O.ssv(sym[a:b], model)
+        r, cc = O.unpack_hits(h)
+        want.append(O.pack_hits(r, cc + np.uint64(a)))
+    want = O.device_order(np.concatenate(want)) if want else np.zeros(0, np.uint64)
+    c.setHitCapacity(max(1 << 16, want.size + 8))
+    c.invokeHavacSsvAsync()
+    state = c.waitForHavacSsvAsync()
+    got = c.getHitList()
+    ok = state == 4 and np.array_equal(got, want)
+    cells += n * nrows
+    hits_total += want.size
+    if not ok:
+        bad += 1
+        print(f"MISMATCH case {case}: nseg={nseg} nrows={nrows} kind={kind} mask={use_mask} got {got.size} want {want.size}", flush=True)
+    if case % 25 == 24:
+        print(f"{case + 1} cases, {bad} mismatches, {cells:.3g} cells, {hits_total} hits, {time.time() - t0:.0f} s", flush=True)
+c.close()
+print(f"SOAK {'FAILED' if bad else 'OK'}: {cases} cases, seed {seed}, {bad} mismatches, {cells:.3g} cells, {hits_total} hits compared element for element")
+sys.exit(1 if bad else 0)
