@@ -80,9 +80,10 @@ constexpr int kMaskSteps = kChunkRows / 2;        // masks are drained twice per
 // sort key of a hit: (segment, row, column-in-segment) -- the FPGA's emission
 // order (device/HavacHls.cpp:151-152,264; device/HitReporting.cpp:178-337)
 __device__ __forceinline__ uint64_t hit_key(uint32_t row, uint64_t column) {
-    uint64_t seg = column / 12288u;
-    uint64_t in_seg = column - seg * 12288u;
-    return (seg << 38) | ((uint64_t)row << 14) | in_seg;
+    // 12288 = 3 * 4096 and columns stay below 2^34 (packed sequence < 4 GiB): a 32-bit division by 3
+    const uint32_t seg = (uint32_t)(column >> 12) / 3u;
+    const uint32_t in_seg = (uint32_t)column - seg * 12288u;
+    return ((uint64_t)seg << 38) | ((uint64_t)row << 14) | in_seg;
 }
 
 // key -> the reference's packed record (device/HitReporting.cpp:421-430)
