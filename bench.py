@@ -4,16 +4,18 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 A step is one whole pass of the hot path over one batch of synthetic input that
-is already resident in HBM: model expansion + SSV kernel + hit compaction +
+is already resident in HBM: model padding copy + SSV kernel + hit compaction +
 ordering of the hit records into the reference's device order (+ for N > 1 the
-RCCL gather of the records to rank 0 and the final ordering there).
+RCCL gather of the records to rank 0, where the rank lists concatenate to the
+ordered whole).
 
 Workload at N = 1 is BASELINE.json configs[1] ("C2"): one pHMM of L = 1024 rows x
 100 Mbp of synthetic sequence (100,012,032 columns after padding to 12288),
 int8 scores, one kernel launch.  For N > 1 the run is WEAK-scaled: the database
-grows to N x 100,012,032 columns and is cut along its diagonals into N shards,
-one per rank (havac_amd/dist.py); every rank holds the whole packed sequence
-(N x 25 MB) in its own HBM, so no data-path collective is needed.
+grows to N x 100,012,032 columns and is cut into N runs of whole 12288-column
+segments, one per rank (havac_amd/dist.py; a rank recomputes a left halo of
+rows-1 columns); every rank holds the whole packed sequence (N x 25 MB) in its
+own HBM, so no data-path collective is needed.
 
 GCUPS = defined DP cells (columns x rows; padding outside the matrix is not
 counted) / wall time of the K timed steps, max over ranks.
@@ -233,7 +235,7 @@ def main():
                              "(C2 = 100 Mbp padded to 12288), int8 SSV, one kernel launch per step"),
                 "rows": nrows, "columns": ncols, "cells_per_step": total_cells, "hits_per_step": nhits,
                 "planted_homologs": planted,
-                "parallelism": f"diagonal-sharded x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} all_gather of hit records" if world > 1 else ""),
+                "parallelism": f"column-sharded x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} gather of hit records to rank 0" if world > 1 else ""),
                 "baseline": "1739 GCUPS = reference README.md:4, 1x Alveo U50 FPGA",
             },
             "kernel": {"name": "ssv_diag_kernel", "avg_ms": round(ssv_ms, 4), "enqueue_to_ordered_ms": round(enq_ms, 4),

@@ -135,7 +135,7 @@ int havac_dev_read_hits(havac_dev *dev, uint64_t *out, uint32_t n);
 
 /* Device time of the last completed run in milliseconds (HIP events on the
  * handle's stream): the SSV kernel alone, and the whole enqueue (model
- * expansion + SSV + hit ordering). */
+ * padding copy + SSV + hit ordering). */
 int havac_dev_last_run_ms(havac_dev *dev, float *ssv_kernel_ms, float *total_ms);
 
 const char *havac_dev_last_error(havac_dev *dev);
@@ -185,8 +185,8 @@ int havac_ssv_set_separator_mask(havac_ssv_ctx *ctx, const uint8_t *d_pair_bitma
  * records were kept and the result is HAVAC_E_HIT_OVERFLOW. */
 int havac_ssv_finish(havac_ssv_ctx *ctx, uint64_t *hit_count_out);
 
-/* Sort `count` packed records in place into device order (used by rank 0 after
- * gathering the shards' hit lists). */
+/* Sort `count` packed records in place into device order (for callers that merge
+ * lists from elsewhere; the shards of havac_ssv_enqueue need no sorting, see above). */
 int havac_ssv_sort_hits(havac_ssv_ctx *ctx, uint64_t *d_hits, uint64_t count, void *hip_stream);
 
 /* After the stream has been synchronised: device time of the last enqueue's
