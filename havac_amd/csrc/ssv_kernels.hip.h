@@ -79,25 +79,26 @@ constexpr int kMaskSteps = kChunkRows / 2;        // masks are drained twice per
 
 // sort key of a hit: (segment, row, column-in-segment) -- the FPGA's emission
 // order (device/HavacHls.cpp:151-152,264; device/HitReporting.cpp:178-337)
-__device__ __forceinline__ uint64_t hit_key(uint32_t row, uint64_t column) {
+// The row field is only as wide as the model needs (row_bits), so that the radix sort has no dead passes.
+__device__ __forceinline__ uint64_t hit_key(uint32_t row, uint64_t column, uint32_t row_bits) {
     // 12288 = 3 * 4096 and columns stay below 2^34 (packed sequence < 4 GiB): a 32-bit division by 3
     const uint32_t seg = (uint32_t)(column >> 12) / 3u;
     const uint32_t in_seg = (uint32_t)column - seg * 12288u;
-    return ((uint64_t)seg << 38) | ((uint64_t)row << 14) | in_seg;
+    return ((uint64_t)seg << (14 + row_bits)) | ((uint64_t)row << 14) | in_seg;
 }
 
 // key -> the reference's packed record (device/HitReporting.cpp:421-430)
-__device__ __forceinline__ uint64_t key_to_record(uint64_t key) {
+__device__ __forceinline__ uint64_t key_to_record(uint64_t key, uint32_t row_bits) {
     uint64_t in_seg = key & 0x3fffull;
-    uint64_t row = (key >> 14) & 0xffffffull;
-    uint64_t seg = key >> 38;
+    uint64_t row = (key >> 14) & ((1ull << row_bits) - 1ull);
+    uint64_t seg = key >> (14 + row_bits);
     return in_seg | (seg << 14) | (row << 40);
 }
-__device__ __forceinline__ uint64_t record_to_key(uint64_t rec) {
+__device__ __forceinline__ uint64_t record_to_key(uint64_t rec, uint32_t row_bits) {
     uint64_t in_seg = rec & 0x3fffull;
     uint64_t seg = (rec >> 14) & 0x3ffffffull;
     uint64_t row = rec >> 40;
-    return (seg << 38) | (row << 14) | in_seg;
+    return (seg << (14 + row_bits)) | (row << 14) | in_seg;
 }
 
 // ---------------------------------------------------------------------------
@@ -151,6 +152,7 @@ struct HitSink {
     uint64_t hit_capacity;
     WaveLds* lds;
     int64_t col_begin, col_end;    // only hits in these columns are reported (the shard's own columns)
+    uint32_t row_bits;             // width of the row field of the sort key
 };
 
 __device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t staged, int lane) {
@@ -195,7 +197,7 @@ __device__ __noinline__ uint32_t drain_steps(const HitSink sink, uint32_t staged
             const unsigned long long writers = __ballot(mine);      // halo columns belong to the neighbouring shard
             if (mine) {
                 const uint32_t pos = staged + __popcll(writers & ((1ull << lane) - 1ull));
-                sink.lds->stage[pos] = hit_key(t - high, (uint64_t)column);
+                sink.lds->stage[pos] = hit_key(t - high, (uint64_t)column, sink.row_bits);
             }
             staged += __popcll(writers);
             if (staged > kHitStage - 32) staged = flush_hits(sink, staged, lane);
@@ -297,7 +299,7 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
                      const uint32_t tile_end, const int64_t col_begin, const int64_t col_end,
                      uint64_t* __restrict__ hits, unsigned long long* __restrict__ hit_count,
                      const uint64_t hit_capacity, const uint32_t* __restrict__ abort_flag,
-                     const uint16_t* __restrict__ pair_mask) {
+                     const uint16_t* __restrict__ pair_mask, const uint32_t row_bits) {
     __shared__ WaveLds wave_lds[kWavesPerBlock];
 
     const int lane = threadIdx.x & 63;
@@ -306,7 +308,7 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
     const uint32_t tile = tile_begin + blockIdx.x * kWavesPerBlock + wave;
     if (tile >= tile_end) return;
     WaveLds* const lds = &wave_lds[wave];
-    const HitSink sink{hits, hit_count, hit_capacity, lds, col_begin, col_end};
+    const HitSink sink{hits, hit_count, hit_capacity, lds, col_begin, col_end, row_bits};
     uint32_t staged = 0;          // wave-uniform
 
     const int64_t d0 = first_diag + (int64_t)tile * kTileDiags;     // wave's first diagonal
@@ -423,13 +425,13 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
 
 // ---------------------------------------------------------------------------
 // after the radix sort of the keys: rewrite them as the reference's records
-__global__ void ssv_keys_to_records(uint64_t* __restrict__ hits, uint64_t n) {
+__global__ void ssv_keys_to_records(uint64_t* __restrict__ hits, uint64_t n, uint32_t row_bits) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) hits[i] = key_to_record(hits[i]);
+    if (i < n) hits[i] = key_to_record(hits[i], row_bits);
 }
-__global__ void ssv_records_to_keys(uint64_t* __restrict__ hits, uint64_t n) {
+__global__ void ssv_records_to_keys(uint64_t* __restrict__ hits, uint64_t n, uint32_t row_bits) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) hits[i] = record_to_key(hits[i]);
+    if (i < n) hits[i] = record_to_key(hits[i], row_bits);
 }
 
 }  // namespace havac
