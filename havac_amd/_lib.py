@@ -22,6 +22,8 @@ STATE_ABORT, STATE_SUBMITTED, STATE_TIMEOUT, STATE_NORESPONSE = 6, 7, 8, 9
 _vp, _u8p, _i8p = C.c_void_p, C.c_void_p, C.c_void_p
 SIGNATURES = {
     "havac_dev_create": (C.c_int, [C.c_uint32, C.POINTER(C.c_void_p)]),
+    "havac_dev_create_multi": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "havac_dev_device_count": (C.c_uint32, [_vp]),
     "havac_dev_destroy": (None, [_vp]),
     "havac_dev_set_hit_capacity": (C.c_int, [_vp, C.c_uint64]),
     "havac_dev_write_sequence": (C.c_int, [_vp, _u8p, C.c_uint64]),

@@ -308,20 +308,30 @@ extern "C" int havac_ssv_last_ms(havac_ssv_ctx* c, float* ssv_kernel_ms, float* 
 // ===========================================================================
 // Level 1: handle API (class HavacHwClient)
 // ===========================================================================
-struct havac_dev {
+// One handle drives one GPU (havac_dev_create) or several (havac_dev_create_multi): every GPU of the handle holds the
+// whole sequence and model and computes one column shard (see shard_columns); because shards are whole segments, the
+// GPUs' ordered hit lists concatenated in shard order are the ordered whole.
+struct DevicePart {
     int device = 0;
     hipStream_t stream = nullptr;
     havac_ssv_ctx* ctx = nullptr;
-    uint8_t* d_seq = nullptr; uint64_t seq_bytes = 0; uint64_t seq_alloc = 0;
-    int8_t* d_phmm = nullptr; uint64_t phmm_bytes = 0; uint64_t phmm_alloc = 0;
-    uint8_t* d_mask = nullptr; uint64_t mask_bytes = 0; uint64_t mask_alloc = 0;   // separator bitmap, optional
-    uint64_t* d_hits = nullptr; uint64_t hit_capacity = 0;
+    uint8_t* d_seq = nullptr; uint64_t seq_alloc = 0;
+    int8_t* d_phmm = nullptr; uint64_t phmm_alloc = 0;
+    uint8_t* d_mask = nullptr; uint64_t mask_alloc = 0;   // separator bitmap, optional
+    uint64_t* d_hits = nullptr;
     uint32_t* d_abort = nullptr;        // device word the kernel polls (cache-bypassing loads)
     hipStream_t abort_stream = nullptr; // abort() writes the word from here while the kernel runs
-    bool abort_requested = false;
     hipEvent_t done = nullptr;
-    bool has_run = false, finished = false, aborted = false, failed = false;
     uint64_t found = 0;
+};
+
+struct havac_dev {
+    std::vector<DevicePart> parts;
+    uint64_t seq_bytes = 0, phmm_bytes = 0, mask_bytes = 0;
+    uint64_t hit_capacity = 0;          // per GPU
+    bool abort_requested = false;
+    bool has_run = false, finished = false, aborted = false, failed = false, overflowed = false;
+    uint64_t found = 0;                 // all GPUs
     std::string err;
 };
 
@@ -329,72 +339,94 @@ struct havac_dev {
 static const uint64_t kDefaultHitCapacity = 14ull * 256ull * 1024ull * 1024ull / sizeof(uint64_t);
 
 static int dev_alloc_hits(havac_dev* d, uint64_t cap) {
-    if (d->d_hits) { (void)hipFree(d->d_hits); d->d_hits = nullptr; d->hit_capacity = 0; }
-    HIP_TRY(d->err, hipMalloc(&d->d_hits, cap * sizeof(uint64_t)));
+    for (DevicePart& p : d->parts) {
+        HIP_TRY(d->err, hipSetDevice(p.device));
+        if (p.d_hits) { (void)hipFree(p.d_hits); p.d_hits = nullptr; }
+        HIP_TRY(d->err, hipMalloc(&p.d_hits, cap * sizeof(uint64_t)));
+    }
     d->hit_capacity = cap;
     return HAVAC_OK;
 }
 
-extern "C" int havac_dev_create(uint32_t device_index, havac_dev** out) {
-    if (!out) return HAVAC_E_ARGUMENT;
+extern "C" int havac_dev_create_multi(const uint32_t* device_indices, uint32_t ndevices, havac_dev** out) {
+    if (!out || !device_indices || ndevices == 0) return HAVAC_E_ARGUMENT;
     *out = nullptr;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || (int)device_index >= ndev) return HAVAC_E_NO_DEVICE;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return HAVAC_E_NO_DEVICE;
+    for (uint32_t i = 0; i < ndevices; i++)
+        if ((int)device_indices[i] >= ndev) return HAVAC_E_NO_DEVICE;
     havac_dev* d = new (std::nothrow) havac_dev;
     if (!d) return HAVAC_E_NOMEM;
-    d->device = (int)device_index;
+    d->parts.resize(ndevices);
     auto fail = [&](int code) { havac_dev_destroy(d); return code; };
-    if (hipSetDevice(d->device) != hipSuccess) return fail(HAVAC_E_NO_DEVICE);
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, d->device) != hipSuccess) return fail(HAVAC_E_NO_DEVICE);
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(HAVAC_E_NO_DEVICE);   // the code object is gfx950 only
-    if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) return fail(HAVAC_E_RUNTIME);
-    if (havac_ssv_ctx_create(&d->ctx) != HAVAC_OK) return fail(HAVAC_E_RUNTIME);
-    if (hipStreamCreateWithFlags(&d->abort_stream, hipStreamNonBlocking) != hipSuccess) return fail(HAVAC_E_RUNTIME);
-    if (hipMalloc(&d->d_abort, sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_NOMEM);
-    if (hipMemset(d->d_abort, 0, sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_RUNTIME);
-    if (hipEventCreateWithFlags(&d->done, hipEventDisableTiming) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+    for (uint32_t i = 0; i < ndevices; i++) {
+        DevicePart& p = d->parts[i];
+        p.device = (int)device_indices[i];
+        if (hipSetDevice(p.device) != hipSuccess) return fail(HAVAC_E_NO_DEVICE);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, p.device) != hipSuccess) return fail(HAVAC_E_NO_DEVICE);
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(HAVAC_E_NO_DEVICE);   // the code object is gfx950 only
+        if (hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+        if (havac_ssv_ctx_create(&p.ctx) != HAVAC_OK) return fail(HAVAC_E_RUNTIME);
+        if (hipStreamCreateWithFlags(&p.abort_stream, hipStreamNonBlocking) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+        if (hipMalloc(&p.d_abort, sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_NOMEM);
+        if (hipMemset(p.d_abort, 0, sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+        if (hipEventCreateWithFlags(&p.done, hipEventDisableTiming) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+    }
     if (dev_alloc_hits(d, kDefaultHitCapacity) != HAVAC_OK) return fail(HAVAC_E_NOMEM);
     *out = d;
     return HAVAC_OK;
 }
 
+extern "C" int havac_dev_create(uint32_t device_index, havac_dev** out) {
+    return havac_dev_create_multi(&device_index, 1, out);
+}
+
 extern "C" void havac_dev_destroy(havac_dev* d) {
     if (!d) return;
-    (void)hipSetDevice(d->device);
-    if (d->stream) (void)hipStreamSynchronize(d->stream);
-    if (d->ctx) havac_ssv_ctx_destroy(d->ctx);
-    if (d->d_seq) (void)hipFree(d->d_seq);
-    if (d->d_phmm) (void)hipFree(d->d_phmm);
-    if (d->d_mask) (void)hipFree(d->d_mask);
-    if (d->d_hits) (void)hipFree(d->d_hits);
-    if (d->d_abort) (void)hipFree(d->d_abort);
-    if (d->abort_stream) (void)hipStreamDestroy(d->abort_stream);
-    if (d->done) (void)hipEventDestroy(d->done);
-    if (d->stream) (void)hipStreamDestroy(d->stream);
+    for (DevicePart& p : d->parts) {
+        (void)hipSetDevice(p.device);
+        if (p.stream) (void)hipStreamSynchronize(p.stream);
+        if (p.ctx) havac_ssv_ctx_destroy(p.ctx);
+        if (p.d_seq) (void)hipFree(p.d_seq);
+        if (p.d_phmm) (void)hipFree(p.d_phmm);
+        if (p.d_mask) (void)hipFree(p.d_mask);
+        if (p.d_hits) (void)hipFree(p.d_hits);
+        if (p.d_abort) (void)hipFree(p.d_abort);
+        if (p.abort_stream) (void)hipStreamDestroy(p.abort_stream);
+        if (p.done) (void)hipEventDestroy(p.done);
+        if (p.stream) (void)hipStreamDestroy(p.stream);
+    }
     delete d;
 }
 
 extern "C" const char* havac_dev_last_error(havac_dev* d) { return d ? d->err.c_str() : "null handle"; }
 
+extern "C" uint32_t havac_dev_device_count(havac_dev* d) { return d ? (uint32_t)d->parts.size() : 0; }
+
 extern "C" int havac_dev_set_hit_capacity(havac_dev* d, uint64_t max_hits) {
     if (!d || max_hits == 0) return HAVAC_E_ARGUMENT;
     if (d->has_run && !d->finished) { d->err = "cannot resize the hit buffer during a run"; return HAVAC_E_LOGIC; }
-    HIP_TRY(d->err, hipSetDevice(d->device));
     return dev_alloc_hits(d, max_hits);
 }
 
+// copies a host buffer to the same-named device buffer of every GPU of the handle
 template <typename T>
-static int upload(havac_dev* d, T** buf, uint64_t* alloc, const void* src, uint64_t nbytes) {
-    HIP_TRY(d->err, hipSetDevice(d->device));
-    if (*alloc < nbytes) {
-        if (*buf) (void)hipFree(*buf);
-        *buf = nullptr; *alloc = 0;
-        HIP_TRY(d->err, hipMalloc(buf, nbytes));
-        *alloc = nbytes;
+static int upload(havac_dev* d, T* DevicePart::*buf, uint64_t DevicePart::*alloc, const void* src, uint64_t nbytes) {
+    for (DevicePart& p : d->parts) {
+        HIP_TRY(d->err, hipSetDevice(p.device));
+        if (p.*alloc < nbytes) {
+            if (p.*buf) (void)hipFree(p.*buf);
+            p.*buf = nullptr; p.*alloc = 0;
+            HIP_TRY(d->err, hipMalloc(&(p.*buf), nbytes));
+            p.*alloc = nbytes;
+        }
+        HIP_TRY(d->err, hipMemcpyAsync(p.*buf, src, nbytes, hipMemcpyHostToDevice, p.stream));
     }
-    HIP_TRY(d->err, hipMemcpyAsync(*buf, src, nbytes, hipMemcpyHostToDevice, d->stream));
-    HIP_TRY(d->err, hipStreamSynchronize(d->stream));
+    for (DevicePart& p : d->parts) {
+        HIP_TRY(d->err, hipSetDevice(p.device));
+        HIP_TRY(d->err, hipStreamSynchronize(p.stream));
+    }
     return HAVAC_OK;
 }
 
@@ -414,7 +446,7 @@ extern "C" int havac_dev_write_sequence(havac_dev* d, const uint8_t* packed, uin
     d->seq_bytes = nbytes;
     d->mask_bytes = 0;                       // a new sequence has no separators until a mask is written for it
     if (nbytes == 0) return HAVAC_OK;
-    return upload(d, &d->d_seq, &d->seq_alloc, packed, nbytes);
+    return upload(d, &DevicePart::d_seq, &DevicePart::seq_alloc, packed, nbytes);
 }
 
 extern "C" int havac_dev_write_separator_mask(havac_dev* d, const uint8_t* pair_bitmap, uint64_t nbytes) {
@@ -426,7 +458,7 @@ extern "C" int havac_dev_write_separator_mask(havac_dev* d, const uint8_t* pair_
         return HAVAC_E_LENGTH;
     }
     d->mask_bytes = nbytes;
-    return upload(d, &d->d_mask, &d->mask_alloc, pair_bitmap, nbytes);
+    return upload(d, &DevicePart::d_mask, &DevicePart::mask_alloc, pair_bitmap, nbytes);
 }
 
 extern "C" int havac_dev_write_phmm(havac_dev* d, const int8_t* scores, uint64_t nbytes) {
@@ -444,7 +476,7 @@ extern "C" int havac_dev_write_phmm(havac_dev* d, const int8_t* scores, uint64_t
     }
     d->phmm_bytes = nbytes;
     if (nbytes == 0) return HAVAC_OK;
-    return upload(d, &d->d_phmm, &d->phmm_alloc, scores, nbytes);
+    return upload(d, &DevicePart::d_phmm, &DevicePart::phmm_alloc, scores, nbytes);
 }
 
 extern "C" int havac_dev_run_async(havac_dev* d) {
@@ -453,33 +485,58 @@ extern "C" int havac_dev_run_async(havac_dev* d) {
     if (d->seq_bytes == 0) { d->err = "sequence length in segments cannot be 0, but 0 was given to the client."; return HAVAC_E_LENGTH; }
     if (d->phmm_bytes == 0) { d->err = "phmm length in vectors cannot be 0, but 0 was given to the client."; return HAVAC_E_LENGTH; }
     if (d->has_run && !d->finished) { d->err = "a run is already in flight"; return HAVAC_E_LOGIC; }
-    HIP_TRY(d->err, hipSetDevice(d->device));
-    HIP_TRY(d->err, hipMemsetAsync(d->d_abort, 0, sizeof(uint32_t), d->stream));
+    const uint32_t nparts = (uint32_t)d->parts.size();
+    if (d->seq_bytes * 4 / HAVAC_SEGMENT_COLUMNS < nparts) {
+        d->err = "the sequence has fewer 12288-column segments than the handle has GPUs";
+        return HAVAC_E_LENGTH;
+    }
     d->abort_requested = false;
-    d->aborted = false; d->failed = false; d->finished = false; d->found = 0;
-    havac_ssv_set_separator_mask(d->ctx, d->mask_bytes ? d->d_mask : nullptr);
-    int rc = havac_ssv_enqueue(d->ctx, d->d_seq, d->seq_bytes * 4, d->d_phmm, (uint32_t)(d->phmm_bytes / 4), 0, 1,
-                               d->d_hits, d->hit_capacity, d->d_abort, d->stream);
-    if (rc) { d->err = havac_ssv_ctx_last_error(d->ctx); return rc; }
-    HIP_TRY(d->err, hipEventRecord(d->done, d->stream));
+    d->aborted = false; d->failed = false; d->finished = false; d->overflowed = false; d->found = 0;
+    for (uint32_t i = 0; i < nparts; i++) {
+        DevicePart& p = d->parts[i];
+        HIP_TRY(d->err, hipSetDevice(p.device));
+        HIP_TRY(d->err, hipMemsetAsync(p.d_abort, 0, sizeof(uint32_t), p.stream));
+        havac_ssv_set_separator_mask(p.ctx, d->mask_bytes ? p.d_mask : nullptr);
+        int rc = havac_ssv_enqueue(p.ctx, p.d_seq, d->seq_bytes * 4, p.d_phmm, (uint32_t)(d->phmm_bytes / 4), i, nparts,
+                                   p.d_hits, d->hit_capacity, p.d_abort, p.stream);
+        if (rc) { d->err = havac_ssv_ctx_last_error(p.ctx); return rc; }
+        HIP_TRY(d->err, hipEventRecord(p.done, p.stream));
+    }
     d->has_run = true;
     return HAVAC_OK;
 }
 
-// completes a drained run: orders the hits
+static int final_state(const havac_dev* d) {
+    return d->failed ? HAVAC_STATE_ERROR : (d->aborted ? HAVAC_STATE_ABORT : HAVAC_STATE_COMPLETED);
+}
+
+// completes a drained run: every GPU orders its own hits
 static int dev_finish(havac_dev* d) {
-    if (d->finished) return d->failed ? HAVAC_STATE_ERROR : (d->aborted ? HAVAC_STATE_ABORT : HAVAC_STATE_COMPLETED);
-    uint64_t found = 0;
-    int rc = havac_ssv_finish(d->ctx, &found);
+    if (d->finished) return final_state(d);
     d->finished = true;
-    d->found = found;
-    d->aborted = d->abort_requested;
-    if (rc != HAVAC_OK) {
-        d->err = havac_ssv_ctx_last_error(d->ctx);
-        d->failed = true;
-        return HAVAC_STATE_ERROR;
+    d->found = 0;
+    for (DevicePart& p : d->parts) {
+        uint64_t found = 0;
+        int rc = havac_ssv_finish(p.ctx, &found);
+        p.found = found;
+        d->found += found;
+        if (rc != HAVAC_OK) {
+            d->err = havac_ssv_ctx_last_error(p.ctx);
+            d->failed = true;
+            if (rc == HAVAC_E_HIT_OVERFLOW) d->overflowed = true;
+        }
     }
-    return d->aborted ? HAVAC_STATE_ABORT : HAVAC_STATE_COMPLETED;
+    d->aborted = d->abort_requested;
+    return final_state(d);
+}
+
+// hipSuccess when every GPU's work has drained, hipErrorNotReady while any has not
+static hipError_t query_all(havac_dev* d) {
+    for (DevicePart& p : d->parts) {
+        hipError_t q = hipEventQuery(p.done);
+        if (q != hipSuccess) return q;
+    }
+    return hipSuccess;
 }
 
 extern "C" int havac_dev_state(havac_dev* d) {
@@ -488,10 +545,18 @@ extern "C" int havac_dev_state(havac_dev* d) {
         d->err = "run object was not initialized. run function invokeHavacSsvAsync to initialize this object.";
         return HAVAC_E_LOGIC;
     }
-    if (d->finished) return d->failed ? HAVAC_STATE_ERROR : (d->aborted ? HAVAC_STATE_ABORT : HAVAC_STATE_COMPLETED);
-    hipError_t q = hipEventQuery(d->done);
+    if (d->finished) return final_state(d);
+    hipError_t q = query_all(d);
     if (q == hipErrorNotReady) return HAVAC_STATE_RUNNING;
     if (q != hipSuccess) { d->err = hip_msg("hipEventQuery", q); return HAVAC_STATE_ERROR; }
+    return dev_finish(d);
+}
+
+static int sync_all(havac_dev* d) {
+    for (DevicePart& p : d->parts) {
+        hipError_t e = hipEventSynchronize(p.done);
+        if (e != hipSuccess) { d->err = hip_msg("hipEventSynchronize", e); d->finished = true; d->failed = true; return HAVAC_STATE_ERROR; }
+    }
     return dev_finish(d);
 }
 
@@ -499,14 +564,10 @@ extern "C" int havac_dev_wait(havac_dev* d, uint32_t timeout_ms) {
     if (!d) return HAVAC_E_ARGUMENT;
     if (!d->has_run) { d->err = "no run to wait for"; return HAVAC_E_LOGIC; }
     if (d->finished) return havac_dev_state(d);
-    if (timeout_ms == 0) {
-        hipError_t e = hipEventSynchronize(d->done);
-        if (e != hipSuccess) { d->err = hip_msg("hipEventSynchronize", e); d->finished = true; d->failed = true; return HAVAC_STATE_ERROR; }
-        return dev_finish(d);
-    }
+    if (timeout_ms == 0) return sync_all(d);
     auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
     for (;;) {
-        hipError_t q = hipEventQuery(d->done);
+        hipError_t q = query_all(d);
         if (q == hipSuccess) return dev_finish(d);
         if (q != hipErrorNotReady) { d->err = hip_msg("hipEventQuery", q); d->finished = true; d->failed = true; return HAVAC_STATE_ERROR; }
         if (std::chrono::steady_clock::now() >= deadline) return HAVAC_STATE_TIMEOUT;
@@ -518,21 +579,23 @@ extern "C" int havac_dev_abort(havac_dev* d) {
     if (!d) return HAVAC_E_ARGUMENT;
     if (!d->has_run) { d->err = "no run to abort"; return HAVAC_E_LOGIC; }
     if (d->finished) return havac_dev_state(d);
-    if (hipEventQuery(d->done) == hipSuccess) return dev_finish(d);
+    if (query_all(d) == hipSuccess) return dev_finish(d);
     static const uint32_t one = 1;
     d->abort_requested = true;
-    hipError_t e = hipMemcpyAsync(d->d_abort, &one, sizeof one, hipMemcpyHostToDevice, d->abort_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(d->abort_stream);
-    if (e == hipSuccess) e = hipEventSynchronize(d->done);
-    if (e != hipSuccess) { d->err = hip_msg("hipEventSynchronize", e); d->finished = true; d->failed = true; return HAVAC_STATE_ERROR; }
-    return dev_finish(d);
+    for (DevicePart& p : d->parts) {
+        hipError_t e = hipSetDevice(p.device);
+        if (e == hipSuccess) e = hipMemcpyAsync(p.d_abort, &one, sizeof one, hipMemcpyHostToDevice, p.abort_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(p.abort_stream);
+        if (e != hipSuccess) { d->err = hip_msg("abort", e); d->finished = true; d->failed = true; return HAVAC_STATE_ERROR; }
+    }
+    return sync_all(d);
 }
 
 extern "C" int havac_dev_num_hits(havac_dev* d, uint32_t* count) {
     if (!d || !count) return HAVAC_E_ARGUMENT;
     if (!d->has_run) { d->err = "num hits was not set by the client!"; return HAVAC_E_RUNTIME; }   // HavacHwClient.cpp:181-183
     if (!d->finished) { int s = havac_dev_wait(d, 0); if (s < 0) return s; }
-    if (d->failed) return d->found > d->hit_capacity ? HAVAC_E_HIT_OVERFLOW : HAVAC_E_RUNTIME;
+    if (d->failed) return d->overflowed ? HAVAC_E_HIT_OVERFLOW : HAVAC_E_RUNTIME;
     *count = (uint32_t)d->found;
     return HAVAC_OK;
 }
@@ -543,14 +606,30 @@ extern "C" int havac_dev_read_hits(havac_dev* d, uint64_t* out, uint32_t n) {
     int rc = havac_dev_num_hits(d, &have);
     if (rc) return rc;
     if (n > have) n = have;
-    if (n == 0) return HAVAC_OK;
-    HIP_TRY(d->err, hipSetDevice(d->device));
-    HIP_TRY(d->err, hipMemcpy(out, d->d_hits, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    // shard order is device order: the GPUs' lists are simply laid end to end
+    uint64_t at = 0;
+    for (DevicePart& p : d->parts) {
+        if (at >= n) break;
+        uint64_t take = p.found < (uint64_t)n - at ? p.found : (uint64_t)n - at;
+        if (take == 0) continue;
+        HIP_TRY(d->err, hipSetDevice(p.device));
+        HIP_TRY(d->err, hipMemcpy(out + at, p.d_hits, (size_t)take * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        at += take;
+    }
     return HAVAC_OK;
 }
 
 extern "C" int havac_dev_last_run_ms(havac_dev* d, float* ssv_kernel_ms, float* total_ms) {
     if (!d) return HAVAC_E_ARGUMENT;
     if (!d->has_run || !d->finished) { d->err = "no finished run"; return HAVAC_E_LOGIC; }
-    return havac_ssv_last_ms(d->ctx, ssv_kernel_ms, total_ms);
+    float k = 0.f, t = 0.f;
+    for (DevicePart& p : d->parts) {     // the slowest GPU
+        float a = 0.f, b = 0.f;
+        havac_ssv_last_ms(p.ctx, &a, &b);
+        if (a > k) k = a;
+        if (b > t) t = b;
+    }
+    if (ssv_kernel_ms) *ssv_kernel_ms = k;
+    if (total_ms) *total_ms = t;
+    return HAVAC_OK;
 }

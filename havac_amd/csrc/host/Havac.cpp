@@ -30,6 +30,18 @@ Havac::Havac(const uint32_t deviceIndex, const float requiredPValue, const std::
     int rc = havac_dev_create(deviceIndex, &dev_);
     if (rc == HAVAC_E_NOMEM) throw std::bad_alloc();
     if (rc != HAVAC_OK) throw std::runtime_error("ERROR: could not open MI355X device " + std::to_string(deviceIndex));
+    init();
+}
+
+Havac::Havac(const std::vector<uint32_t> &deviceIndices, const float requiredPValue)
+    : deviceIndex(deviceIndices.empty() ? 0 : deviceIndices[0]), requiredPValue(requiredPValue) {
+    int rc = havac_dev_create_multi(deviceIndices.data(), (uint32_t)deviceIndices.size(), &dev_);
+    if (rc == HAVAC_E_NOMEM) throw std::bad_alloc();
+    if (rc != HAVAC_OK) throw std::runtime_error("ERROR: could not open the requested MI355X devices");
+    init();
+}
+
+void Havac::init() {
     fastaVector = static_cast<FastaVector *>(std::malloc(sizeof(FastaVector)));
     p7HmmList = static_cast<P7HmmList *>(std::calloc(1, sizeof(P7HmmList)));
     if (!fastaVector || !p7HmmList || fastaVectorInit(fastaVector) == FASTA_VECTOR_ALLOCATION_FAIL) {

@@ -55,6 +55,9 @@ class Havac {       // host/Havac.hpp:42-107
 public:
     Havac(const uint32_t deviceIndex = 0, const float requiredPValue = 0.02f,
           const std::string xclbinSrc = xclbinSrcDefault);
+    // addition: one object over several GPUs of a node, one column shard each (the reference has one deviceIndex per
+    // object); everything else behaves the same, getHitsFromFinishedRun returns the same list in the same order
+    Havac(const std::vector<uint32_t> &deviceIndices, const float requiredPValue = 0.02f);
     Havac(Havac &&havac) = delete;
     Havac(Havac &havac) = delete;
     ~Havac();
@@ -83,6 +86,7 @@ public:
 
 private:
     void check(int code);                                  // C-ABI code -> the reference's exception types
+    void init();
     vector<uint32_t> generatePhmmLenPrefixSums();
 
     havac_dev *dev_ = nullptr;

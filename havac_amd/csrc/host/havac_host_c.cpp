@@ -59,6 +59,17 @@ int havac_host_create(uint32_t device_index, float p, havac_host **out) {
     return HAVAC_OK;
 }
 
+int havac_host_create_multi(const uint32_t *devices, uint32_t n, float p, havac_host **out) {
+    if (!out || !devices || n == 0) return HAVAC_E_ARGUMENT;
+    *out = nullptr;
+    havac_host *h = new (std::nothrow) havac_host;
+    if (!h) return HAVAC_E_NOMEM;
+    int rc = guarded(h, [&] { h->obj = new Havac(std::vector<uint32_t>(devices, devices + n), p); });
+    if (rc != HAVAC_OK) { delete h; return rc == HAVAC_E_RUNTIME ? HAVAC_E_NO_DEVICE : rc; }
+    *out = h;
+    return HAVAC_OK;
+}
+
 void havac_host_destroy(havac_host *h) {
     if (!h) return;
     delete h->obj;

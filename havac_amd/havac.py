@@ -22,6 +22,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "libhavac.so")
 _vp = C.c_void_p
 HOST_SIGNATURES = {
     "havac_host_create": (C.c_int, [C.c_uint32, C.c_float, C.POINTER(C.c_void_p)]),
+    "havac_host_create_multi": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint32, C.c_float, C.POINTER(C.c_void_p)]),
     "havac_host_destroy": (None, [_vp]),
     "havac_host_load_sequence": (C.c_int, [_vp, C.c_char_p]),
     "havac_host_load_phmm": (C.c_int, [_vp, C.c_char_p]),
@@ -84,10 +85,15 @@ def _hits_from_arrays(sp, si, pp, pi):
 
 
 class Havac:
-    def __init__(self, deviceIndex: int = 0, requiredPValue: float = 0.02, xclbinSrc: str = ""):
+    def __init__(self, deviceIndex: int = 0, requiredPValue: float = 0.02, xclbinSrc: str = "", deviceIndices=None):
+        """deviceIndices (an addition): several GPUs behind one object, one column shard each."""
         self._L = load_host()
         h = C.c_void_p()
-        rc = self._L.havac_host_create(deviceIndex, requiredPValue, C.byref(h))
+        if deviceIndices is not None:
+            arr = (C.c_uint32 * len(deviceIndices))(*deviceIndices)
+            rc = self._L.havac_host_create_multi(arr, len(deviceIndices), requiredPValue, C.byref(h))
+        else:
+            rc = self._L.havac_host_create(deviceIndex, requiredPValue, C.byref(h))
         if rc != 0:
             raise_for(rc, "could not create Havac (no gfx950 device?)")
         self._h = h

@@ -53,10 +53,16 @@ class HavacHwClient:
     """HavacHwClient(xclbinFileSrc, havacKernelName, deviceIndex) -- the first two are accepted and
     ignored: there is no bitstream, the kernels live in libhavac_dev.so."""
 
-    def __init__(self, xclbinFileSrc: str = "", havacKernelName: str = "HavacKernel", deviceIndex: int = 0):
+    def __init__(self, xclbinFileSrc: str = "", havacKernelName: str = "HavacKernel", deviceIndex: int = 0,
+                 deviceIndices=None):
+        """deviceIndices (an addition): several GPUs behind one client, one column shard each."""
         self._L = _lib.load()
         h = C.c_void_p()
-        rc = self._L.havac_dev_create(deviceIndex, C.byref(h))
+        if deviceIndices is not None:
+            arr = (C.c_uint32 * len(deviceIndices))(*deviceIndices)
+            rc = self._L.havac_dev_create_multi(arr, len(deviceIndices), C.byref(h))
+        else:
+            rc = self._L.havac_dev_create(deviceIndex, C.byref(h))
         if rc != 0:
             raise_for(rc, "could not create the device client")
         self._h = h

@@ -89,6 +89,13 @@ typedef struct havac_dev havac_dev;
  * capacity, 14*256 MiB = 469,762,048 records (host/HavacHwClient.hpp:94);
  * see havac_dev_set_hit_capacity. */
 int havac_dev_create(uint32_t device_index, havac_dev **out);
+/* The same handle over several GPUs of one node (the reference has one deviceIndex per
+ * object, host/Havac.hpp:51).  Every GPU receives the whole sequence and model; GPU i computes column shard i of
+ * ndevices (see havac_ssv_enqueue); havac_dev_read_hits lays the GPUs' ordered lists end to end, which is the
+ * reference's device order of the whole.  All other entry points behave as for one GPU; the hit capacity is per
+ * GPU.  A device index may be repeated (several shards on one GPU). */
+int havac_dev_create_multi(const uint32_t *device_indices, uint32_t ndevices, havac_dev **out);
+uint32_t havac_dev_device_count(havac_dev *dev);
 void havac_dev_destroy(havac_dev *dev);
 
 /* Change the hit-buffer capacity (records). */

@@ -21,6 +21,8 @@ typedef struct havac_host havac_host;
 
 /* Havac::Havac(deviceIndex, requiredPValue, xclbinSrc)  host/Havac.cpp:20-31 */
 int havac_host_create(uint32_t device_index, float required_p_value, havac_host **out);
+/* Havac over several GPUs of one node, one column shard each (an addition; include/havac_dev.h) */
+int havac_host_create_multi(const uint32_t *device_indices, uint32_t ndevices, float required_p_value, havac_host **out);
 void havac_host_destroy(havac_host *h);
 int havac_host_load_sequence(havac_host *h, const char *fasta_path);   /* Havac::loadSequence  :57-77 */
 int havac_host_load_phmm(havac_host *h, const char *hmm_path);         /* Havac::loadPhmm      :42-55 */

@@ -219,3 +219,42 @@ def test_limits_of_the_record_format(client):
     client.writePhmm(np.zeros(((1 << 24) * 4,), np.int8))          # 2^24 rows: one more than the record can name
     with pytest.raises(LengthError, match="below 2\\^24"):
         client.invokeHavacSsvAsync()
+
+
+def test_one_handle_over_several_gpus(oracle, tmp_path):
+    """havac_dev_create_multi: several device parts behind one handle, one column shard each.
+    The box has one GPU, so the same device is named several times: same code path, same answer, same order."""
+    from havac_amd.hw_client import HavacHwClient, LengthError
+    sym, model = small_inputs(nrows=700, nseg=7, seed=31)
+    want = oracle.ssv_mt(sym, model)
+    for devices in ([0, 0], [0, 0, 0], [0] * 7):
+        c = HavacHwClient(deviceIndices=devices)
+        c.setHitCapacity(want.size + 8)
+        c.writeSequence(synth.pack_2bit(sym))
+        c.writePhmm(model)
+        c.invokeHavacSsvAsync()
+        assert c.waitForHavacSsvAsync() == 4
+        assert c.getNumHits() == want.size
+        assert np.array_equal(c.getHitList(), want)
+        c.close()
+    c = HavacHwClient(deviceIndices=[0] * 8)                      # more GPUs than segments
+    c.writeSequence(synth.pack_2bit(sym))
+    c.writePhmm(model)
+    with pytest.raises(LengthError, match="fewer 12288-column segments"):
+        c.invokeHavacSsvAsync()
+    c.close()
+    # and through the C++ Havac class
+    from havac_amd import havac
+    fa, hmm = write_inputs(tmp_path, [90, 310], [20000, 30000, 9000], seed=17)
+    single = havac.Havac(0, 0.02)
+    multi = havac.Havac(requiredPValue=0.02, deviceIndices=[0, 0, 0])
+    import ctypes as C
+    for h in (single, multi):
+        h.loadPhmm(hmm)
+        C.CDLL(None).srand(5)
+        h.loadSequence(fa)
+        h.runHardwareClient()
+    a, b = single.getHitsFromFinishedRun(), multi.getHitsFromFinishedRun()
+    assert len(a) > 20 and a == b
+    assert np.array_equal(single.rawHits(), multi.rawHits())
+    single.close(); multi.close()
