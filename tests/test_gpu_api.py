@@ -258,3 +258,21 @@ def test_one_handle_over_several_gpus(oracle, tmp_path):
     assert len(a) > 20 and a == b
     assert np.array_equal(single.rawHits(), multi.rawHits())
     single.close(); multi.close()
+
+
+def test_native_software_testbench(tmp_path):
+    """tests/native/software_testbench.cpp: the reference's C-simulation testbench flow
+    (device/test/softwareTestbench.cpp:49-306) in C++ against the C ABI, 2 tests x 3 segments as there."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from oracle import pyoracle
+    pyoracle.build(with_ref=False)
+    exe = str(tmp_path / "software_testbench")
+    lib_dir, oracle_dir = os.path.join(ROOT, "havac_amd"), os.path.join(ROOT, "oracle")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "native", "software_testbench.cpp"), "-o", exe,
+                    f"-L{lib_dir}", "-lhavac_dev", f"-L{oracle_dir}", "-loracle",
+                    f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{oracle_dir}"], check=True)
+    out = subprocess.run([exe, "2", "3", "2000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "ALL TESTS PASSED" in out.stdout and out.stdout.count("passed") >= 2
