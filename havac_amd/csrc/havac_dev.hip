@@ -499,7 +499,14 @@ extern "C" int havac_dev_run_async(havac_dev* d) {
         havac_ssv_set_separator_mask(p.ctx, d->mask_bytes ? p.d_mask : nullptr);
         int rc = havac_ssv_enqueue(p.ctx, p.d_seq, d->seq_bytes * 4, p.d_phmm, (uint32_t)(d->phmm_bytes / 4), i, nparts,
                                    p.d_hits, d->hit_capacity, p.d_abort, p.stream);
-        if (rc) { d->err = havac_ssv_ctx_last_error(p.ctx); return rc; }
+        if (rc) {
+            d->err = havac_ssv_ctx_last_error(p.ctx);
+            for (uint32_t j = 0; j < i; j++) {            // take back what the earlier GPUs were given
+                (void)hipSetDevice(d->parts[j].device);
+                (void)havac_ssv_finish(d->parts[j].ctx, nullptr);
+            }
+            return rc;
+        }
         HIP_TRY(d->err, hipEventRecord(p.done, p.stream));
     }
     d->has_run = true;
