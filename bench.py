@@ -227,7 +227,7 @@ def main():
             "metric": "GCUPS (billion SSV cells/s); hit-list bit-exact vs softSsv",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": round(gcups / FPGA_GCUPS, 3), "dtype": "i16 (packed pairs over int8 scores)",
+            "vs_baseline": round(gcups / FPGA_GCUPS, 3), "dtype": "i16",
             "data": "synthetic",
             "config": {
                 "workload": (("C2: " if (nrows == ROWS and args.columns_per_gpu == COLUMNS_PER_GPU) else "custom: ") +
@@ -245,6 +245,9 @@ def main():
                 "unit": "Tiop/s (int16 saturating adds, 1 per cell; the score select is served by LDS)",
                 "frac": round(achieved_tiops / PEAK_TIOPS_I16, 4),
                 "frac_vs_full_rate_class_peak": round(achieved_tiops / PEAK_TIOPS_I16_FULL_RATE_CLASS, 4),
+                # SURVEY.md 8d wrote the VALU fraction as GCUPS*1e9*2/3.93e13 (select AND add on the VALU, 32-bit lanes);
+                # it exceeds 1 here because the select is served by LDS
+                "frac_by_survey_8d_formula": round(my_cells / kernel_s * 2 / 3.93e13, 4),
                 "traffic": args.traffic_bytes if args.traffic_bytes is not None else (
                     PMC_TRAFFIC_C2_BYTES if (world == 1 and nrows == ROWS and args.columns_per_gpu == COLUMNS_PER_GPU) else None),
                 "lds": {"bound": "lds", "achieved": round(my_cells * LDS_BYTES_PER_CELL / kernel_s / 1e12, 2),
