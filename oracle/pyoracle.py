@@ -59,6 +59,8 @@ def lib():
                                               C.c_uint64, _u64p, C.c_uint64]
         L.havac_oracle_ssv_mt.restype = C.c_int64
         L.havac_oracle_ssv_mt.argtypes = [_u8p, C.c_uint64, _i8p, C.c_uint64, _u64p, C.c_uint64, C.c_int]
+        L.havac_oracle_ssv_fast.restype = C.c_int64
+        L.havac_oracle_ssv_fast.argtypes = [_u8p, C.c_uint64, _i8p, C.c_uint64, _u64p, C.c_uint64, C.c_int]
         L.havac_oracle_sort_device_order.argtypes = [_u64p, C.c_uint64]
         L.havac_oracle_sort_row_major.argtypes = [_u64p, C.c_uint64]
         _lib = L
@@ -156,6 +158,21 @@ def ssv_mt(symbols, model, nthreads=0, cap=None) -> np.ndarray:
     while True:
         buf = np.empty(cap, dtype=np.uint64)
         n = lib().havac_oracle_ssv_mt(symbols, symbols.size, model, model.size // 4, buf, cap, nthreads)
+        if n < 0:
+            raise MemoryError("oracle could not allocate")
+        if n <= cap:
+            return buf[:n].copy()
+        cap = int(n)
+
+
+def ssv_fast(symbols, model, nthreads=0, cap=None) -> np.ndarray:
+    """AVX2 + threads; the whole matrix, records in DEVICE order.  For full-size comparisons."""
+    symbols = np.ascontiguousarray(symbols, dtype=np.uint8)
+    model = np.ascontiguousarray(model, dtype=np.int8).reshape(-1)
+    cap = int(cap if cap is not None else max(1024, symbols.size // 64))
+    while True:
+        buf = np.empty(cap, dtype=np.uint64)
+        n = lib().havac_oracle_ssv_fast(symbols, symbols.size, model, model.size // 4, buf, cap, nthreads)
         if n < 0:
             raise MemoryError("oracle could not allocate")
         if n <= cap:

@@ -63,6 +63,34 @@ def test_c2_full_size_windows_and_repeatability(torch_dev, oracle):
     assert np.array_equal(got, again)
 
 
+def test_c2_full_size_whole_hit_list(torch_dev, oracle):
+    """Config C2, every one of its 1.02e11 cells: the complete hit list of the launch against the oracle's
+    vectorised whole-matrix route (oracle.ssv_fast; itself pinned to the plain sweep and the reference object in
+    tests/test_oracle.py).  Element for element, in device order."""
+    import os
+    torch, dev = torch_dev
+    model, cons = synth.dfam_like_model(1024, synth.SEED_MODEL)
+    packed = synth.random_packed(100_012_032, synth.SEED_SEQUENCE)
+    got = run_shards(torch, dev, packed, model)[0]
+    sym = synth.unpack_2bit(packed)
+    want = oracle.ssv_fast(sym, model, nthreads=min(16, os.cpu_count() or 1), cap=1 << 21)
+    assert got.size == want.size
+    assert np.array_equal(got, want)
+
+
+def test_c3_shape_whole_hit_list(torch_dev, oracle):
+    """Config C3's shape (hundreds of concatenated models) at a size the vectorised oracle finishes in seconds:
+    ~60k rows x 1.2 Mbp = 7.4e10 cells, whole list."""
+    import os
+    torch, dev = torch_dev
+    model, cons = synth.model_collection(synth.model_lengths(120), 2101)
+    n = 100 * synth.SEGMENT
+    packed = synth.random_packed(n, 1303)
+    got = run_shards(torch, dev, packed, model, capacity=1 << 23)[0]
+    want = oracle.ssv_fast(synth.unpack_2bit(packed), model, nthreads=min(16, os.cpu_count() or 1), cap=1 << 22)
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_shard_union_equals_whole(torch_dev, oracle, world):
     """The column shards the multi-GPU path uses: concatenated in shard order they ARE the single-launch answer."""

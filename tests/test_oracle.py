@@ -73,6 +73,7 @@ def test_golden_fixture(oracle, name):
     sym = oracle.unpack_2bit(packed)
     assert np.array_equal(oracle.ssv(sym, model), hits)
     assert np.array_equal(oracle.ssv_mt(sym, model, nthreads=3), hits)
+    assert np.array_equal(oracle.ssv_fast(sym, model, nthreads=3), hits)
 
 
 @pytest.mark.parametrize("name", ["g2_L1024_3seg_cross", "g5d_random_full_range"])
@@ -102,3 +103,25 @@ def test_restatement_equals_reference_when_built(oracle):
     # the reference's own emission order: rows ascending, columns descending (SoftSsv.cpp:31-32)
     rows, cols = oracle.ssv_reference_raw(np.zeros(5, np.uint8), np.full((3, 4), 127, np.int8))
     assert list(zip(rows.tolist(), cols.tolist())) == [(2, 4), (2, 3), (2, 2)]
+
+
+def test_fast_route_equals_plain_sweep(oracle):
+    """havac_oracle_ssv_fast (AVX2 tiles + threads) is a second route to the same records: ragged sizes around its
+    8192-column tile and 16-cell vector, models taller than a tile is wide, extreme scores."""
+    rng = np.random.default_rng(21)
+    shapes = [(1, 1), (1, 17), (5, 15), (300, 8191), (300, 8192), (300, 8193), (9000, 20_000), (1024, 70_001), (33, 16_400)]
+    for k, (nrows, n) in enumerate(shapes):
+        if k % 3 == 0:
+            model = rng.integers(-128, 128, size=(nrows, 4)).astype(np.int8)
+        elif k % 3 == 1:
+            model = synth.dfam_like_model(nrows, 50 + k)[0]
+        else:
+            model = rng.choice(np.array([-128, 127, 126, 1, 0], np.int8), size=(nrows, 4))
+        sym = rng.integers(0, 4, size=n, dtype=np.uint8)
+        want = oracle.ssv(sym, model)
+        for threads in (1, 5):
+            assert np.array_equal(oracle.ssv_fast(sym, model, nthreads=threads), want), (nrows, n, threads)
+    if oracle.ref_available():
+        model = np.full((40, 4), 127, np.int8)
+        sym = rng.integers(0, 4, size=30_000, dtype=np.uint8)
+        assert np.array_equal(oracle.ssv_fast(sym, model), oracle.ssv_reference(sym, model))
