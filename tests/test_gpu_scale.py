@@ -44,6 +44,18 @@ def check_windows(oracle, packed, model, got, windows):
         assert np.array_equal(oracle.device_order(mine), oracle.device_order(want)), (lo, hi, mine.size, want.size)
 
 
+def whole_list(oracle, packed, model, lo=0, hi=None):
+    """Every record of columns [lo, hi) from the oracle's vectorised route (lo a multiple of 4)."""
+    import os
+    hi = packed.size * 4 if hi is None else hi
+    start = max(0, lo - (model.shape[0] - 1)) // 4 * 4
+    sym = synth.unpack_2bit(packed[start // 4: (hi + 3) // 4])[: hi - start]
+    recs = oracle.ssv_fast(sym, model, nthreads=min(16, os.cpu_count() or 1), cap=1 << 22)
+    rows, cols = oracle.unpack_hits(recs)
+    keep = cols + np.uint64(start) >= np.uint64(lo)
+    return oracle.device_order(oracle.pack_hits(rows[keep], cols[keep] + np.uint64(start)))
+
+
 def test_c2_full_size_windows_and_repeatability(torch_dev, oracle):
     """Config C2: L=1024 x 100,012,032 columns in one launch; exact check on windows spread over the matrix
     (including both ends and segment boundaries), hit count plausibility, and run-to-run identity."""
@@ -121,6 +133,7 @@ def test_c5_long_model_windows(torch_dev, oracle):
     got = run_shards(torch, dev, packed, model, capacity=1 << 23)[0]
     assert got.size > 100_000
     check_windows(oracle, packed, model, got, [(0, 3000), (n - 3000, n), (5_000_000, 5_003_000)])
+    assert np.array_equal(got, whole_list(oracle, packed, model))         # all 2.0e11 cells
 
 
 def test_c3_many_models_windows(torch_dev, oracle):
@@ -191,3 +204,4 @@ def test_c4_shape_one_shard_of_eight(torch_dev, oracle):
     assert found > 1_000_000 and int(cols.min()) >= lo and int(cols.max()) < hi
     assert np.array_equal(got, oracle.device_order(got))
     check_windows(oracle, packed, model, got, [(lo, lo + 20_000), (hi - 20_000, hi), ((lo + hi) // 2 // 4 * 4, (lo + hi) // 2 // 4 * 4 + 20_000)])
+    assert np.array_equal(got, whole_list(oracle, packed, model, lo, hi))  # the shard's 3.75e11 cells, every record

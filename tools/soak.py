@@ -1,6 +1,8 @@
 """Randomised soak of the HIP path against the CPU checker: many small problems of random shape and score
 distribution (and random separator masks), compared element for element.  A one-off confidence run, not part
-of the test suite:   python tools/soak.py [cases] [seed]"""
+of the test suite:   python tools/soak.py [cases] [seed] [big]
+With `big`, problems are 50-2500 segments x up to 25000 rows of Dfam-like models (up to ~6e11 cells each) and the
+checker is the oracle's vectorised whole-matrix route."""
 import os
 import sys
 import time
@@ -16,6 +18,7 @@ from oracle import pyoracle as O  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 rng = np.random.default_rng(seed)
 c = HavacHwClient()
 bad = 0
@@ -26,6 +29,11 @@ for case in range(cases):
     n = nseg * synth.SEGMENT
     nrows = int(rng.choice([1, 2, 3, 31, 32, 33, 64, 100, 255, 256, 257, 1000, 2048, 2049, 4100, int(rng.integers(1, 3000))]))
     kind = int(rng.integers(0, 6))
+    if big:
+        nseg = int(rng.integers(50, 2500))
+        n = nseg * synth.SEGMENT
+        nrows = int(rng.choice([100, 1024, 2047, 2048, 2049, 5000, 25000, int(rng.integers(1, 12000))]))
+        kind = int(rng.choice([1, 5]))
     if kind == 0:
         model = rng.integers(-128, 128, size=(nrows, 4)).astype(np.int8)
     elif kind == 1:
@@ -61,7 +69,10 @@ for case in range(cases):
     c.writePhmm(model)
     want = []
     for a, b in pieces:
-        h = O.ssv_mt(sym[a:b], model) if (b - a) * nrows > 5e7 else O.ssv(sym[a:b], model)
+        if big:
+            h = O.ssv_fast(sym[a:b], model, nthreads=16, cap=1 << 22)
+        else:
+            h = O.ssv_mt(sym[a:b], model) if (b - a) * nrows > 5e7 else O.ssv(sym[a:b], model)
         r, cc = O.unpack_hits(h)
         want.append(O.pack_hits(r, cc + np.uint64(a)))
     want = O.device_order(np.concatenate(want)) if want else np.zeros(0, np.uint64)
@@ -75,7 +86,7 @@ for case in range(cases):
     if not ok:
         bad += 1
         print(f"MISMATCH case {case}: nseg={nseg} nrows={nrows} kind={kind} mask={use_mask} got {got.size} want {want.size}", flush=True)
-    if case % 25 == 24:
+    if case % (5 if big else 25) == (4 if big else 24):
         print(f"{case + 1} cases, {bad} mismatches, {cells:.3g} cells, {hits_total} hits, {time.time() - t0:.0f} s", flush=True)
 c.close()
 print(f"SOAK {'FAILED' if bad else 'OK'}: {cases} cases, seed {seed}, {bad} mismatches, {cells:.3g} cells, {hits_total} hits compared element for element")
