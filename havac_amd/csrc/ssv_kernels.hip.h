@@ -253,25 +253,21 @@ __device__ __forceinline__ void step_pair(uint32_t (&cur)[kRegs], uint32_t (&nxt
         uint32_t any_first = 0;
 #pragma unroll
         for (int i = 0; i < kRegs; i++) any_first |= cur[i];
-        uint32_t mask0 = 0, mask1;
+        uint32_t mask0 = 0;
         if (__any((any_first & kCrossedBits) != 0)) {
-            mask0 = crossed_mask(cur);                                // crossed 256 on the first step
-            mask1 = crossed_mask(nxt) & ~mask0;                       // on the second (a first-step mark is still on nxt)
-            // a cell that crossed on the first step restarts from 0 (SoftSsv.cpp:43-44): redo its second step
+            // crossed 256 on the first step: such a cell holds exactly 0x7fff and restarts from 0
+            // (SoftSsv.cpp:43-44); + 1 makes it 0x8000 = score 0, then its second step is taken again
+            mask0 = crossed_mask(cur);
 #pragma unroll
             for (int i = 0; i < kRegs; i++) {
-                const uint32_t s0 = (cur[i] & kCrossedBits) * 0xffffu;  // 0xffff over each cell marked on the first step
-                const uint32_t sx = (nxt[i] & kCrossedBits) * 0xffffu;  // ... marked on either step
-                const uint32_t fresh = sat_add_pk16(kScoreZero, match_words<P>(C[P + i]).y);
-                const uint32_t repl = (fresh & s0) | (kScoreZero & ~s0);
-                nxt[i] = (repl & sx) | (nxt[i] & ~sx);
+                cur[i] += cur[i] & kCrossedBits;
+                nxt[i] = sat_add_pk16(cur[i], match_words<P>(C[P + i]).y);
             }
-        } else {
-            // only second-step crossings: those cells hold exactly 0x7fff; + 1 makes it 0x8000 = score 0
-            mask1 = crossed_mask(nxt);
-#pragma unroll
-            for (int i = 0; i < kRegs; i++) nxt[i] += nxt[i] & kCrossedBits;
         }
+        // second-step crossings: the same + 1
+        const uint32_t mask1 = crossed_mask(nxt);
+#pragma unroll
+        for (int i = 0; i < kRegs; i++) nxt[i] += nxt[i] & kCrossedBits;
         constexpr int r = (2 * P) % kMaskSteps;
         masks[r * 64 + lane] = mask0;
         masks[(r + 1) * 64 + lane] = mask1;
