@@ -244,6 +244,68 @@ vector<HavacHit> Havac::getHitsFromFinishedRun() {
     return out;
 }
 
+vector<HavacWindow> havacMergeHitsToWindows(const vector<HavacHit> &hits, const vector<uint32_t> &modelLengths,
+                                            const vector<uint64_t> &recordLengths, uint32_t flank) {
+    vector<HavacWindow> stretches;
+    stretches.reserve(hits.size());
+    for (const HavacHit &h : hits) {
+        if (h.phmmIndex >= modelLengths.size() || h.sequenceIndex >= recordLengths.size()) continue;
+        const uint64_t n = recordLengths[h.sequenceIndex];
+        const uint64_t length = modelLengths[h.phmmIndex];
+        if (n == 0 || length == 0) continue;
+        const uint64_t i = std::min<uint64_t>(h.sequencePosition, n - 1);   // a hit on the terminator column
+        const uint64_t k = std::min<uint64_t>(h.phmmPosition, length - 1);
+        const uint64_t before = (h.reverseStrand ? length - 1 - k : k) + flank;
+        const uint64_t after = (h.reverseStrand ? k : length - 1 - k) + flank;
+        HavacWindow w;
+        w.sequenceIndex = h.sequenceIndex;
+        w.phmmIndex = h.phmmIndex;
+        w.reverseStrand = h.reverseStrand;
+        w.sequenceStart = i > before ? i - before : 0;
+        w.sequenceEnd = std::min<uint64_t>(i + after, n - 1);
+        w.phmmFirst = w.phmmLast = (uint32_t)k;
+        w.hitCount = 1;
+        stretches.push_back(w);
+    }
+    std::sort(stretches.begin(), stretches.end(), [](const HavacWindow &a, const HavacWindow &b) {
+        if (a.sequenceIndex != b.sequenceIndex) return a.sequenceIndex < b.sequenceIndex;
+        if (a.reverseStrand != b.reverseStrand) return b.reverseStrand;
+        if (a.phmmIndex != b.phmmIndex) return a.phmmIndex < b.phmmIndex;
+        if (a.sequenceStart != b.sequenceStart) return a.sequenceStart < b.sequenceStart;
+        return a.sequenceEnd < b.sequenceEnd;
+    });
+    vector<HavacWindow> out;
+    for (const HavacWindow &w : stretches) {
+        if (!out.empty()) {
+            HavacWindow &last = out.back();
+            if (last.sequenceIndex == w.sequenceIndex && last.reverseStrand == w.reverseStrand &&
+                last.phmmIndex == w.phmmIndex && w.sequenceStart <= last.sequenceEnd + 1) {
+                last.sequenceEnd = std::max(last.sequenceEnd, w.sequenceEnd);
+                last.phmmFirst = std::min(last.phmmFirst, w.phmmFirst);
+                last.phmmLast = std::max(last.phmmLast, w.phmmLast);
+                last.hitCount += 1;
+                continue;
+            }
+        }
+        out.push_back(w);
+    }
+    return out;
+}
+
+vector<HavacWindow> Havac::getWindowsFromFinishedRun(uint32_t flank) {
+    vector<HavacHit> hits = getHitsFromFinishedRun();
+    vector<uint32_t> modelLengths;
+    for (uint32_t i = 0; i < p7HmmList->count; i++) modelLengths.push_back(p7HmmList->phmms[i].header.modelLength);
+    vector<uint64_t> recordLengths;
+    size_t start = 0;
+    for (size_t i = 0; i < fastaVector->metadata.count; i++) {          // end position is one past the terminator
+        const size_t end = fastaVector->metadata.data[i].sequenceEndPosition;
+        recordLengths.push_back(end > start ? end - start - 1 : 0);
+        start = end;
+    }
+    return havacMergeHitsToWindows(hits, modelLengths, recordLengths, flank);
+}
+
 HavacHit::HavacHit(const uint64_t sequencePosition, const uint32_t sequenceIndex, const uint32_t phmmPosition,
                    const uint32_t phmmIndex)
     : sequencePosition(sequencePosition), sequenceIndex(sequenceIndex), phmmPosition(phmmPosition), phmmIndex(phmmIndex) {}

@@ -49,6 +49,20 @@ public:
     std::string toString();
 };
 
+// Addition (second half): what a long-target pipeline does with SSV hits before the
+// next filter stage -- every hit becomes the stretch of its record the model would cover along the hit's
+// diagonal, stretched by a flank, and overlapping stretches of the same (record, strand, model) are merged
+// (nhmmer's window list after its SSV stage; the reference stops at the hit list and its validation tool only
+// tests hits against nhmmer's envelopes, test/hmmerValidation/hmmerValidation.cpp:77-132).
+struct HavacWindow {
+    uint32_t sequenceIndex;
+    uint32_t phmmIndex;
+    bool reverseStrand;
+    uint64_t sequenceStart, sequenceEnd;   // inclusive, positions on the record as it stands in the file
+    uint32_t phmmFirst, phmmLast;          // lowest / highest model position among the window's hits
+    uint32_t hitCount;
+};
+
 struct havac_dev;   // include/havac_dev.h
 
 class Havac {       // host/Havac.hpp:42-107
@@ -80,6 +94,8 @@ public:
     // does by default and the reference's benchmark switched off (--watson, benchmark/readme.txt:62-64).  Hits of
     // that half carry reverseStrand = true.  Call before loadSequence.  Default off.
     void setBothStrands(bool on);
+    // Hits of the finished run merged into windows (see HavacWindow); `flank` residues are added on both sides.
+    vector<HavacWindow> getWindowsFromFinishedRun(uint32_t flank = 0);
     void setHitCapacity(uint64_t maxHits);                 // the reference's buffer is a fixed 3.5 GiB
     void lastRunMilliseconds(float *ssvKernelMs, float *totalMs);
     const vector<uint64_t> &rawHitsOfLastFetch() const { return rawHits_; }
@@ -112,4 +128,12 @@ struct PhmmLocalPosition { int32_t phmmIndex; uint32_t phmmPosition; };
 PhmmLocalPosition phmmPrefixSumsBinarySearch(uint32_t phmmGlobalPosition, vector<uint32_t> &prefixSums);
 vector<HavacHit> havacResolveHits(const vector<uint64_t> &rawHits, const FastaVector *fastaVector,
                                   vector<uint32_t> &phmmPrefixSums);
+
+// Hits -> merged windows, as a free function (testable without a device).  A hit at model position k (0-based, model
+// length L) and record position i covers [i - k, i + (L-1-k)] on the forward strand and [i - (L-1-k), i + k] on the
+// reverse strand (there the model runs towards lower file positions); the stretch is widened by `flank`, clipped to
+// the record [0, recordLength), and stretches of one (record, strand, model) that overlap or touch become one window.
+// Output order: record, strand (forward first), model, start.
+vector<HavacWindow> havacMergeHitsToWindows(const vector<HavacHit> &hits, const vector<uint32_t> &modelLengths,
+                                            const vector<uint64_t> &recordLengths, uint32_t flank = 0);
 #endif

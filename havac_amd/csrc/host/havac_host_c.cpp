@@ -109,6 +109,46 @@ int havac_host_get_hits(havac_host *h, uint64_t *sp, uint32_t *si, uint32_t *pp,
     return copyHits(h->hits, sp, si, pp, pi, cap, count);
 }
 
+static int copyWindows(const vector<HavacWindow> &w, uint32_t *si, uint32_t *pi, uint8_t *rs, uint64_t *start,
+                       uint64_t *end, uint32_t *pf, uint32_t *pl, uint32_t *hc, uint32_t cap, uint32_t *count) {
+    if (count) *count = (uint32_t)w.size();
+    for (uint32_t i = 0; i < cap && i < w.size(); i++) {
+        si[i] = w[i].sequenceIndex; pi[i] = w[i].phmmIndex; rs[i] = w[i].reverseStrand ? 1 : 0;
+        start[i] = w[i].sequenceStart; end[i] = w[i].sequenceEnd;
+        pf[i] = w[i].phmmFirst; pl[i] = w[i].phmmLast; hc[i] = w[i].hitCount;
+    }
+    return HAVAC_OK;
+}
+
+int havac_host_get_windows(havac_host *h, uint32_t flank, uint32_t *si, uint32_t *pi, uint8_t *rs, uint64_t *start,
+                           uint64_t *end, uint32_t *pf, uint32_t *pl, uint32_t *hc, uint32_t cap, uint32_t *count) {
+    vector<HavacWindow> w;
+    int rc = guarded(h, [&] { w = h->obj->getWindowsFromFinishedRun(flank); });
+    if (rc != HAVAC_OK) return rc;
+    return copyWindows(w, si, pi, rs, start, end, pf, pl, hc, cap, count);
+}
+
+int havac_host_merge_windows(const uint64_t *sp, const uint32_t *sidx, const uint32_t *pp, const uint32_t *pidx,
+                             const uint8_t *reverse, uint32_t nhits, const uint32_t *modelLengths, uint32_t nmodels,
+                             const uint64_t *recordLengths, uint32_t nrecords, uint32_t flank, uint32_t *si,
+                             uint32_t *pi, uint8_t *rs, uint64_t *start, uint64_t *end, uint32_t *pf, uint32_t *pl,
+                             uint32_t *hc, uint32_t cap, uint32_t *count) {
+    try {
+        vector<HavacHit> hits;
+        hits.reserve(nhits);
+        for (uint32_t i = 0; i < nhits; i++) {
+            HavacHit hit(sp[i], sidx[i], pp[i], pidx[i]);
+            hit.reverseStrand = reverse && reverse[i];
+            hits.push_back(hit);
+        }
+        vector<HavacWindow> w = havacMergeHitsToWindows(hits, vector<uint32_t>(modelLengths, modelLengths + nmodels),
+                                                        vector<uint64_t>(recordLengths, recordLengths + nrecords), flank);
+        return copyWindows(w, si, pi, rs, start, end, pf, pl, hc, cap, count);
+    } catch (const std::bad_alloc &) {
+        return HAVAC_E_NOMEM;
+    }
+}
+
 int havac_host_get_raw_hits(havac_host *h, uint64_t *out, uint32_t cap, uint32_t *count) {
     const vector<uint64_t> &raw = h->obj->rawHitsOfLastFetch();
     if (count) *count = (uint32_t)raw.size();

@@ -47,6 +47,10 @@ HOST_SIGNATURES = {
     "havac_host_project_score": (C.c_float, [C.c_float, C.c_float]),
     "havac_host_resolve_hits": (C.c_int, [C.c_char_p, C.c_char_p, _vp, C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint32,
                                           C.POINTER(C.c_uint32)]),
+    "havac_host_merge_windows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32,
+                                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "havac_host_get_windows": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32,
+                                         C.POINTER(C.c_uint32)]),
 }
 
 _host = None
@@ -153,6 +157,14 @@ class Havac:
         self._check(self._L.havac_host_get_hit_strands(self._h, rev.ctypes.data, n.value, C.byref(n)))
         return [HavacHit(int(a), int(b), int(c), int(d), bool(e)) for a, b, c, d, e in zip(sp, si, pp, pi, rev)]
 
+    def getWindowsFromFinishedRun(self, flank: int = 0):
+        """Not in the reference: the run's hits merged into windows (Havac.hpp: HavacWindow)."""
+        n = C.c_uint32(0)
+        self._check(self._L.havac_host_get_windows(self._h, flank, *([None] * 8), 0, C.byref(n)))
+        arrays = _window_arrays(n.value)
+        self._check(self._L.havac_host_get_windows(self._h, flank, *[a.ctypes.data for a in arrays], n.value, C.byref(n)))
+        return _windows_from_arrays(arrays, n.value)
+
     def rawHits(self) -> np.ndarray:
         n = C.c_uint32(0)
         self._check(self._L.havac_host_get_raw_hits(self._h, None, 0, C.byref(n)))
@@ -164,6 +176,29 @@ class Havac:
         a, b = C.c_float(0), C.c_float(0)
         self._check(self._L.havac_host_last_run_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+
+@dataclass(frozen=True)
+class HavacWindow:   # Havac.hpp: HavacWindow (not in the reference)
+    sequenceIndex: int
+    phmmIndex: int
+    reverseStrand: bool
+    sequenceStart: int
+    sequenceEnd: int
+    phmmFirst: int
+    phmmLast: int
+    hitCount: int
+
+
+def _window_arrays(n):
+    return [np.empty(n, np.uint32), np.empty(n, np.uint32), np.empty(n, np.uint8), np.empty(n, np.uint64),
+            np.empty(n, np.uint64), np.empty(n, np.uint32), np.empty(n, np.uint32), np.empty(n, np.uint32)]
+
+
+def _windows_from_arrays(arrays, n):
+    si, pi, rs, st, en, pf, pl, hc = arrays
+    return [HavacWindow(int(si[i]), int(pi[i]), bool(rs[i]), int(st[i]), int(en[i]), int(pf[i]), int(pl[i]), int(hc[i]))
+            for i in range(n)]
 
 
 # ---- host-only stages (no device) --------------------------------------------
@@ -218,3 +253,23 @@ def resolve_hits(fasta_path: str, hmm_path: str, raw: np.ndarray):
         raise_for(rc, "could not resolve hits")
     k = n.value
     return _hits_from_arrays(sp[:k], si[:k], pp[:k], pi[:k])
+
+
+def merge_windows(hits, model_lengths, record_lengths, flank: int = 0):
+    """havacMergeHitsToWindows: a list of HavacHit -> merged HavacWindow list."""
+    L = load_host()
+    sp = np.array([h.sequencePosition for h in hits], np.uint64)
+    si = np.array([h.sequenceIndex for h in hits], np.uint32)
+    pp = np.array([h.phmmPosition for h in hits], np.uint32)
+    pi = np.array([h.phmmIndex for h in hits], np.uint32)
+    rs = np.array([1 if h.reverseStrand else 0 for h in hits], np.uint8)
+    ml = np.ascontiguousarray(model_lengths, np.uint32)
+    rl = np.ascontiguousarray(record_lengths, np.uint64)
+    arrays = _window_arrays(len(hits))
+    n = C.c_uint32(0)
+    rc = L.havac_host_merge_windows(sp.ctypes.data, si.ctypes.data, pp.ctypes.data, pi.ctypes.data, rs.ctypes.data,
+                                    len(hits), ml.ctypes.data, ml.size, rl.ctypes.data, rl.size, flank,
+                                    *[a.ctypes.data for a in arrays], len(hits), C.byref(n))
+    if rc != 0:
+        raise_for(rc, "could not merge windows")
+    return _windows_from_arrays(arrays, n.value)

@@ -68,6 +68,20 @@ int havac_host_resolve_hits(const char *fasta_path, const char *hmm_path, const 
                             uint64_t *sequence_position, uint32_t *sequence_index, uint32_t *phmm_position,
                             uint32_t *phmm_index, uint32_t cap, uint32_t *count);
 
+/* Hits -> merged windows (Havac.hpp: havacMergeHitsToWindows).  `reverse_strand` may
+ * be NULL (all forward).  Writes at most `cap` windows into the seven output arrays, *count = windows found. */
+int havac_host_merge_windows(const uint64_t *sequence_position, const uint32_t *sequence_index,
+                             const uint32_t *phmm_position, const uint32_t *phmm_index, const uint8_t *reverse_strand,
+                             uint32_t nhits, const uint32_t *model_lengths, uint32_t nmodels,
+                             const uint64_t *record_lengths, uint32_t nrecords, uint32_t flank,
+                             uint32_t *w_sequence_index, uint32_t *w_phmm_index, uint8_t *w_reverse_strand,
+                             uint64_t *w_start, uint64_t *w_end, uint32_t *w_phmm_first, uint32_t *w_phmm_last,
+                             uint32_t *w_hit_count, uint32_t cap, uint32_t *count);
+/* The same on a handle's finished run (Havac::getWindowsFromFinishedRun). */
+int havac_host_get_windows(havac_host *h, uint32_t flank, uint32_t *w_sequence_index, uint32_t *w_phmm_index,
+                           uint8_t *w_reverse_strand, uint64_t *w_start, uint64_t *w_end, uint32_t *w_phmm_first,
+                           uint32_t *w_phmm_last, uint32_t *w_hit_count, uint32_t cap, uint32_t *count);
+
 #ifdef __cplusplus
 }
 #endif

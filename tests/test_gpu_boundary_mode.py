@@ -191,3 +191,29 @@ def test_boundary_mode_with_both_strands(tmp_path, oracle):
     h.close()
     assert len(got) == len(hits) and len(want) > 40
     assert got == want
+
+
+def test_windows_of_a_run_cover_the_planted_homologs(tmp_path, oracle):
+    """f3, second half: Havac::getWindowsFromFinishedRun on both strands = the host merge applied to the run's own
+    hit list, and every hit lies inside a window of its own record, model and strand."""
+    import ctypes as C
+    from havac_amd import havac
+    from test_gpu_api import write_inputs
+    lengths = [30000, 12000]
+    fa, hmm = write_inputs(tmp_path, [150, 300], lengths, seed=21)
+    table, lens = havac.project_hmm(hmm, 0.02)
+    h = havac.Havac(0, 0.02)
+    h.setBoundaryMode(True)
+    h.setBothStrands(True)
+    h.loadPhmm(hmm)
+    C.CDLL(None).srand(5)
+    h.loadSequence(fa)
+    h.runHardwareClient()
+    hits = h.getHitsFromFinishedRun()
+    windows = h.getWindowsFromFinishedRun(20)
+    assert windows == havac.merge_windows(hits, lens, lengths, 20)
+    assert len(windows) > 0 and sum(w.hitCount for w in windows) == len(hits)
+    for x in hits:                                            # every hit lies inside a window of its own key
+        assert any(w.sequenceIndex == x.sequenceIndex and w.phmmIndex == x.phmmIndex and w.reverseStrand == x.reverseStrand
+                   and w.sequenceStart <= min(x.sequencePosition, lengths[x.sequenceIndex] - 1) <= w.sequenceEnd for w in windows)
+    h.close()

@@ -209,3 +209,61 @@ def test_fasta_reader_against_a_plain_python_parse(tmp_path):
         want = lut[np.frombuffer(r.encode(), dtype=np.uint8)]
         assert np.array_equal(sym[at:at + len(r)], want)
         at += len(r) + 1                                    # the terminator column holds a random nucleotide
+
+
+def _windows_by_hand(hits, model_lengths, record_lengths, flank):
+    """the definition in Havac.hpp (havacMergeHitsToWindows), written as a union of stretches on a position set"""
+    from collections import defaultdict
+    covered = defaultdict(set)
+    members = defaultdict(list)
+    for h in hits:
+        n, L = record_lengths[h.sequenceIndex], model_lengths[h.phmmIndex]
+        i, k = min(h.sequencePosition, n - 1), h.phmmPosition
+        before, after = (L - 1 - k, k) if h.reverseStrand else (k, L - 1 - k)
+        lo, hi = max(0, i - before - flank), min(n - 1, i + after + flank)
+        key = (h.sequenceIndex, h.reverseStrand, h.phmmIndex)
+        covered[key].update(range(lo, hi + 1))
+        members[key].append((lo, k))
+    out = []
+    for key in sorted(covered):
+        pos = sorted(covered[key])
+        runs, start = [], pos[0]
+        for a, b in zip(pos, pos[1:] + [None]):
+            if b is None or b != a + 1:
+                runs.append((start, a))
+                start = b
+        for lo, hi in runs:
+            inside = [k for (s, k) in members[key] if lo <= s <= hi]
+            out.append(havac.HavacWindow(key[0], key[2], key[1], lo, hi, min(inside), max(inside), len(inside)))
+    return out
+
+
+def test_hits_merge_into_windows():
+    """SURVEY.md section 8 row f3 (second half): stretches along the hit diagonals, merged per (record, strand, model)."""
+    rng = np.random.default_rng(8)
+    model_lengths = [30, 120, 7]
+    record_lengths = [500, 40, 2000, 1]
+    for flank in (0, 5, 60):
+        hits = []
+        for _ in range(300):
+            m = int(rng.integers(0, 3))
+            r = int(rng.integers(0, 4))
+            hits.append(havac.HavacHit(int(rng.integers(0, record_lengths[r] + 1)), r, int(rng.integers(0, model_lengths[m])),
+                                       m, bool(rng.integers(0, 2))))
+        got = havac.merge_windows(hits, model_lengths, record_lengths, flank)
+        assert got == _windows_by_hand(hits, model_lengths, record_lengths, flank)
+        assert sum(w.hitCount for w in got) == len(hits)
+        keys = [(w.sequenceIndex, w.reverseStrand, w.phmmIndex, w.sequenceStart) for w in got]
+        assert keys == sorted(keys)
+        for a, b in zip(got, got[1:]):                          # windows of one key neither overlap nor touch
+            if (a.sequenceIndex, a.reverseStrand, a.phmmIndex) == (b.sequenceIndex, b.reverseStrand, b.phmmIndex):
+                assert b.sequenceStart > a.sequenceEnd + 1
+    # one forward hit: model position 10 of 30 at record position 100 covers [90, 119]; the mirrored stretch on the
+    # reverse strand is [81, 110]
+    one = havac.merge_windows([havac.HavacHit(100, 0, 10, 0)], model_lengths, record_lengths)
+    assert (one[0].sequenceStart, one[0].sequenceEnd, one[0].hitCount) == (90, 119, 1)
+    rev = havac.merge_windows([havac.HavacHit(100, 0, 10, 0, True)], model_lengths, record_lengths)
+    assert (rev[0].sequenceStart, rev[0].sequenceEnd, rev[0].reverseStrand) == (81, 110, True)
+    assert havac.merge_windows([], model_lengths, record_lengths) == []
+    # hits naming a model or record that does not exist are dropped, not an error
+    assert havac.merge_windows([havac.HavacHit(1, 9, 0, 0), havac.HavacHit(1, 0, 0, 9)], model_lengths, record_lengths) == []
