@@ -7,7 +7,12 @@ A step is one whole pass of the hot path over one batch of synthetic input that
 is already resident in HBM: model padding copy + SSV kernel + hit compaction +
 ordering of the hit records into the reference's device order (+ for N > 1 the
 RCCL gather of the records to rank 0, where the rank lists concatenate to the
-ordered whole).
+ordered whole).  By default three passes are in flight (--pipeline-depth), each with its own
+context, hit buffer and HIP stream: while the host waits for the hit count of pass k, orders
+its records and gathers them, the SSV kernel of pass k+1 runs; the SSV kernels themselves are
+chained back to back, never side by side, so their event-timed durations stay clean.  All K
+passes are complete when the timed region ends; `config.ms_per_step_strictly_serial` shows
+the same K passes with one in flight.
 
 Workload at N = 1 is BASELINE.json configs[1] ("C2"): one pHMM of L = 1024 rows x
 100 Mbp of synthetic sequence (100,012,032 columns after padding to 12288),
@@ -144,6 +149,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--columns-per-gpu", type=int, default=COLUMNS_PER_GPU)
+    ap.add_argument("--pipeline-depth", type=int, default=3,
+                    help="passes in flight (own context, hit buffer and stream each): the ordering / gather of pass k "
+                         "overlaps the SSV kernel of pass k+1; the SSV kernels stay back to back.  1 = strictly serial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cols-per-core", type=int, default=500_000)
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -193,28 +201,47 @@ def main():
     d_phmm = torch.from_numpy(model.reshape(-1)).to(device)
 
     hit_capacity = max(1 << 20, int(args.columns_per_gpu * nrows * 4e-5))
-    engine = ShardedSsv(hit_capacity, device)
+    depth = max(1, args.pipeline_depth)
+    engine = ShardedSsv(hit_capacity, device, depth=depth)
     my_cells = shard_cells(ncols, nrows, rank, world)
     total_cells = ncols * nrows
-
-    def step():
-        return engine.run(d_seq, ncols, d_phmm, nrows)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(engine, nsteps):
+        """`nsteps` whole passes, all finished on return -> (last result, per-pass (kernel ms, enqueue-to-ordered ms))"""
+        result, timings = None, []
+        for _ in range(nsteps):
+            engine.submit(d_seq, ncols, d_phmm, nrows)
+            if len(engine.in_flight) == len(engine.slots):
+                result = engine.collect()
+                timings.append(engine.ctx.last_ms())
+        while engine.in_flight:
+            result = engine.collect()
+            timings.append(engine.ctx.last_ms())
+        return result, timings
+
+    run_steps(engine, args.warmup)
     fence()
-    kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        merged, found = step()
-        kernel_ms.append(engine.ctx.last_ms())
+    (merged, found), kernel_ms = run_steps(engine, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    if rank == 0 and merged is not None:
+        merged = merged.clone()
+    serial_ms, serial_timings = None, kernel_ms
+    if depth > 1:       # the same steps strictly one after the other, for the record (not `value`)
+        serial = ShardedSsv(hit_capacity, device, depth=1)
+        run_steps(serial, 2)
+        fence()
+        t1 = time.perf_counter()
+        _, serial_timings = run_steps(serial, args.steps)
+        fence()
+        serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        serial.close()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -224,7 +251,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         gcups = total_cells / (elapsed / args.steps) / 1e9
         ssv_ms = float(np.mean([k[0] for k in kernel_ms]))
-        enq_ms = float(np.mean([k[1] for k in kernel_ms]))
+        enq_ms = float(np.mean([k[1] for k in serial_timings]))   # of the strictly serial passes: no queueing in it
         nhits = int(merged.numel())
         hits_np = merged.cpu().numpy().view(np.uint64)
         # algorithmic HBM bytes of this rank's launch: its share of the packed sequence once, the
@@ -243,7 +270,8 @@ def main():
                              f"1 pHMM L={nrows} x {args.columns_per_gpu} columns per GPU "
                              "(C2 = 100 Mbp padded to 12288), int8 SSV, one kernel launch per step"),
                 "rows": nrows, "columns": ncols, "cells_per_step": total_cells, "hits_per_step": nhits,
-                "planted_homologs": planted,
+                "planted_homologs": planted, "passes_in_flight": depth,
+                "ms_per_step_strictly_serial": None if serial_ms is None else round(serial_ms, 4),
                 "parallelism": f"column-sharded x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} gather of hit records to rank 0" if world > 1 else ""),
                 "baseline": "1739 GCUPS = reference README.md:4, 1x Alveo U50 FPGA",
             },

@@ -47,24 +47,73 @@ def gather_hits(local_hits: torch.Tensor, local_count: int, group=None):
     return torch.cat([p[:c] for p, c in zip(parts, counts)]).to(out_dev), counts
 
 
-class ShardedSsv:
-    """Rank-local driver: enqueue this rank's shard, order its hits, gather to rank 0 (already in order)."""
-
-    def __init__(self, hit_capacity: int, device: torch.device):
+class _Slot:
+    def __init__(self, hit_capacity, device, own_stream):
         from .ssv import SsvContext
         self.ctx = SsvContext()
-        self.device = device
         self.hits = torch.empty(hit_capacity, dtype=torch.int64, device=device)
+        self.stream = torch.cuda.Stream(device) if own_stream else None
+        self.kernel_done = None          # recorded behind the SSV kernel of the pass in flight
+
+
+class ShardedSsv:
+    """Rank-local driver: enqueue this rank's shard, order its hits, gather to rank 0 (already in order).
+
+    depth > 1 keeps that many passes in flight, each with its own context, hit buffer and HIP stream:
+    ``submit`` enqueues a pass, ``collect`` finishes the oldest one.  While the host waits for pass k's hit count,
+    orders its records and (N > 1) gathers them over RCCL, the SSV kernel of pass k+1 is already running.  The SSV
+    kernels themselves are kept back to back, never side by side (pass k+1 waits for the kernel of pass k), so a
+    kernel's event-timed duration stays the duration of that kernel alone."""
+
+    def __init__(self, hit_capacity: int, device: torch.device, depth: int = 1, back_to_back: bool = True):
+        self.device = device
+        self.back_to_back = back_to_back
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.slots = [_Slot(hit_capacity, device, depth > 1) for _ in range(max(1, depth))]
+        self.in_flight = []               # slot indices, oldest first
+        self.next_slot = 0
+        self.last_kernel_done = None
+        self.ctx = self.slots[0].ctx      # the context of the most recently collected pass (for last_ms)
+        self.hits = self.slots[0].hits
+
+    def submit(self, d_seq: torch.Tensor, nsymbols: int, d_phmm: torch.Tensor, nrows: int):
+        if len(self.in_flight) == len(self.slots):
+            raise RuntimeError("every slot is in flight: collect() first")
+        slot = self.slots[self.next_slot]
+        stream = slot.stream if slot.stream is not None else torch.cuda.current_stream(self.device)
+        if slot.stream is not None:
+            stream.wait_stream(torch.cuda.current_stream(self.device))      # the caller's inputs
+            if self.back_to_back and self.last_kernel_done is not None:
+                stream.wait_event(self.last_kernel_done)
+        slot.ctx.enqueue(d_seq.data_ptr(), nsymbols, d_phmm.data_ptr(), nrows, slot.hits.data_ptr(),
+                         slot.hits.numel(), self.rank, self.world, 0, stream.cuda_stream)
+        if slot.stream is not None:
+            slot.kernel_done = torch.cuda.Event()
+            slot.kernel_done.record(stream)
+            self.last_kernel_done = slot.kernel_done
+        self.in_flight.append(self.next_slot)
+        self.next_slot = (self.next_slot + 1) % len(self.slots)
+
+    def collect(self):
+        """-> (records on rank 0 in device order or None, hits found by this rank) of the oldest pass in flight"""
+        slot = self.slots[self.in_flight.pop(0)]
+        found = slot.ctx.finish()
+        self.ctx, self.hits = slot.ctx, slot.hits
+        if self.world == 1:
+            return slot.hits[:found], found
+        if slot.stream is None:
+            merged, _ = gather_hits(slot.hits, found)
+        else:
+            with torch.cuda.stream(slot.stream):
+                merged, _ = gather_hits(slot.hits, found)
+        return merged, found
 
     def run(self, d_seq: torch.Tensor, nsymbols: int, d_phmm: torch.Tensor, nrows: int):
-        """-> (records on rank 0 in device order or None, hits found by this rank)"""
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.ctx.enqueue(d_seq.data_ptr(), nsymbols, d_phmm.data_ptr(), nrows, self.hits.data_ptr(),
-                         self.hits.numel(), self.rank, self.world, 0, stream)
-        found = self.ctx.finish()
-        if self.world == 1:
-            return self.hits[:found], found
-        merged, _ = gather_hits(self.hits, found)
-        return merged, found
+        """one pass, start to end -> (records on rank 0 in device order or None, hits found by this rank)"""
+        self.submit(d_seq, nsymbols, d_phmm, nrows)
+        return self.collect()
+
+    def close(self):
+        for slot in self.slots:
+            slot.ctx.close()

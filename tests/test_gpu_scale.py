@@ -205,3 +205,36 @@ def test_c4_shape_one_shard_of_eight(torch_dev, oracle):
     assert np.array_equal(got, oracle.device_order(got))
     check_windows(oracle, packed, model, got, [(lo, lo + 20_000), (hi - 20_000, hi), ((lo + hi) // 2 // 4 * 4, (lo + hi) // 2 // 4 * 4 + 20_000)])
     assert np.array_equal(got, whole_list(oracle, packed, model, lo, hi))  # the shard's 3.75e11 cells, every record
+
+
+def test_passes_in_flight_give_the_same_lists(torch_dev, oracle):
+    """ShardedSsv with several passes in flight (bench.py's default): six different problems submitted through
+    three slots come back in submission order, each equal to its own oracle list."""
+    torch, dev = torch_dev
+    from havac_amd.dist import ShardedSsv
+    eng = ShardedSsv(1 << 20, dev, depth=3)
+    problems = []
+    for k in range(6):
+        model, cons = synth.model_collection([200 + 37 * k, 90], 600 + k)
+        sym = synth.random_symbols((3 + k) * synth.SEGMENT, 700 + k)
+        synth.plant_homologs(sym, cons, sym.size, every=9000, length=150, seed=k)
+        problems.append((torch.from_numpy(synth.pack_2bit(sym)).to(dev), sym.size,
+                         torch.from_numpy(model.reshape(-1)).to(dev), model.shape[0], oracle.ssv_mt(sym, model)))
+    got = []
+    for d_seq, n, d_phmm, nrows, _ in problems:
+        if len(eng.in_flight) == 3:
+            hits, found = eng.collect()
+            got.append(hits.cpu().numpy().view(np.uint64).copy())
+        eng.submit(d_seq, n, d_phmm, nrows)
+    while eng.in_flight:
+        hits, found = eng.collect()
+        got.append(hits.cpu().numpy().view(np.uint64).copy())
+    with pytest.raises(RuntimeError):
+        for _ in range(4):
+            eng.submit(*problems[0][:4])
+    while eng.in_flight:
+        eng.collect()
+    eng.close()
+    assert len(got) == 6
+    for (_, _, _, _, want), mine in zip(problems, got):
+        assert want.size > 0 and np.array_equal(mine, want)
