@@ -155,6 +155,12 @@ struct HitSink {
     uint32_t row_bits;             // width of the row field of the sort key
 };
 
+__device__ __forceinline__ int64_t uniform_i64(int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t staged, int lane) {
     if (staged == 0) return 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -176,31 +182,40 @@ __device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t sta
 // stands for register 2*(q & 7) + (q >> 4), cell (q >> 3) & 1 (see crossed_mask).
 // At step t the low cell of register g of lane l is (row t, column c) and the
 // high cell (row t - 1, column c), with c = wave_diag0 + 32*l + 2*g + t.
-__device__ __noinline__ uint32_t drain_steps(const HitSink sink, uint32_t staged, uint32_t steps_with_hits,
-                                             uint32_t step0, int64_t wave_diag0, int lane) {
+__device__ __noinline__ uint32_t drain_steps(const HitSink sink, uint32_t staged_in, uint32_t steps_in,
+                                             uint32_t step0_in, int64_t wave_diag0_in, int lane) {
+    // Arguments arrive in VGPRs; everything but `lane` is wave-uniform.  Back into SGPRs: the loops below then run
+    // on the scalar unit, which this VALU-bound kernel leaves idle; per hit the VALU only moves the record to LDS.
+    uint32_t staged = __builtin_amdgcn_readfirstlane(staged_in);
+    uint32_t steps_with_hits = __builtin_amdgcn_readfirstlane(steps_in);
+    const uint32_t step0 = __builtin_amdgcn_readfirstlane(step0_in);
+    const int64_t wave_diag0 = uniform_i64(wave_diag0_in);
+    const int64_t col_begin = uniform_i64(sink.col_begin), col_end = uniform_i64(sink.col_end);
+    const uint32_t row_bits = __builtin_amdgcn_readfirstlane(sink.row_bits);
+    const auto lds = (__attribute__((address_space(3))) WaveLds*)sink.lds;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     while (steps_with_hits) {
-        const int r = __builtin_ctz(steps_with_hits);
+        const uint32_t r = (uint32_t)__builtin_ctz(steps_with_hits);
         steps_with_hits &= steps_with_hits - 1;
         const uint32_t t = step0 + r;
-        const uint32_t mask = sink.lds->masks[r * 64 + lane];
+        const uint32_t mask = lds->masks[r * 64 + lane];
         unsigned long long lanes = __ballot(mask != 0);
         while (lanes) {
-            const int src = __builtin_ctzll(lanes);
+            const uint32_t src = (uint32_t)__builtin_ctzll(lanes);
             lanes &= lanes - 1;
-            const uint32_t m = __builtin_amdgcn_readlane(mask, src);
-            // lane q < 32 looks at bit q: register 2*(q & 7) + (q >> 4), cell (q >> 3) & 1
-            const int reg = 2 * (lane & 7) + ((lane >> 4) & 1);
-            const int high = (lane >> 3) & 1;
-            const int64_t column = wave_diag0 + 32 * src + 2 * reg + (int64_t)t;
-            const bool mine = lane < 32 && ((m >> lane) & 1u) && column >= sink.col_begin && column < sink.col_end;
-            const unsigned long long writers = __ballot(mine);      // halo columns belong to the neighbouring shard
-            if (mine) {
-                const uint32_t pos = staged + __popcll(writers & ((1ull << lane) - 1ull));
-                sink.lds->stage[pos] = hit_key(t - high, (uint64_t)column, sink.row_bits);
+            uint32_t m = __builtin_amdgcn_readlane(mask, src);
+            while (m) {
+                const uint32_t q = (uint32_t)__builtin_ctz(m);      // bit q: register 2*(q & 7) + (q >> 4), cell (q >> 3) & 1
+                m &= m - 1;
+                const uint32_t reg = 2 * (q & 7) + (q >> 4);
+                const uint32_t high = (q >> 3) & 1;
+                const int64_t column = wave_diag0 + (int64_t)(32 * src + 2 * reg + t);
+                if (column < col_begin || column >= col_end) continue;   // halo columns belong to the neighbouring shard
+                const uint64_t key = hit_key(t - high, (uint64_t)column, row_bits);
+                if (lane == 0) lds->stage[staged] = key;
+                staged++;
+                if (staged == kHitStage) staged = flush_hits(sink, staged, lane);
             }
-            staged += __popcll(writers);
-            if (staged > kHitStage - 32) staged = flush_hits(sink, staged, lane);
         }
     }
     return staged;
