@@ -198,83 +198,90 @@ int64_t havac_oracle_ssv_mt(const uint8_t *symbols, uint64_t n, const int8_t *mo
     return total;
 }
 
-/* ---- AVX2 tiles --------------------------------------------------------- */
+/* ---- AVX2 diagonal bands ------------------------------------------------ */
 #if defined(__x86_64__)
 #include <immintrin.h>
 
-/* tile width in columns: the two row buffers of a tile (tile + nrows bytes each) stay in L1/L2, and the left halo
- * of nrows-1 columns every tile recomputes stays a modest share of it */
-static uint64_t fast_tile_width(uint64_t nrows) {
-    uint64_t w = 8192;
-    while (w < 2 * nrows) w *= 2;
-    return w;
-}
+/* A cell depends only on its own diagonal d = s - p, so the matrix is cut into bands of
+ * FAST_BAND consecutive diagonals that never exchange anything: a band keeps one score byte per diagonal (L1
+ * resident), and row p updates it in place from the symbols at columns d + p.  No halo, exactly n * nrows cell
+ * updates.  Bands are dealt to the threads round robin; every thread collects its records in a growing buffer, sorts
+ * them by device-order key, and the lists are merged at the end. */
+#define FAST_BAND 16384
 
 struct fast_job {
     const uint8_t *symbols; uint64_t n; const int8_t *model; uint64_t nrows;
-    uint64_t tile, tile_begin, tile_end;      /* tiles [tile_begin, tile_end) of `tile` columns */
-    uint64_t *hits; uint64_t cap; int64_t found;
+    uint64_t nbands; int thread, nthreads;
+    uint64_t *keys; uint64_t count, room; int failed;
 };
 
-/* one tile: columns [a, b) of the matrix, swept from column a - (nrows-1) (or 0); two row buffers in L1 */
+static uint64_t device_key_of(uint64_t row, uint64_t column) {
+    return (column / HAVAC_ORACLE_SEGMENT) << 38 | row << 14 | (column % HAVAC_ORACLE_SEGMENT);
+}
+
+static void fast_emit(struct fast_job *j, uint64_t row, uint64_t column) {
+    if (j->count == j->room) {
+        uint64_t room = j->room ? 2 * j->room : 4096;
+        uint64_t *grown = (uint64_t *)realloc(j->keys, (size_t)room * sizeof(uint64_t));
+        if (!grown) { j->failed = 1; return; }
+        j->keys = grown; j->room = room;
+    }
+    j->keys[j->count++] = device_key_of(row, column);
+}
+
+/* diagonals [d0, d0 + FAST_BAND) of the matrix, d0 may be negative */
 __attribute__((target("avx2")))
-static int64_t fast_tile(const struct fast_job *j, uint64_t a, uint64_t b, uint8_t *buf0, uint8_t *buf1,
-                         uint64_t *hits, uint64_t cap, uint64_t found) {
-    const uint64_t halo = j->nrows - 1;
-    const uint64_t start = a > halo ? a - halo : 0;
-    const uint64_t width = b - start;
-    const uint8_t *sym = j->symbols + start;
-    /* buffers hold the previous row shifted by one: prev[s] is the score of column s-1; prev[0] = 0 (column `start`
-       sees 0: the matrix edge, or a diagonal that starts on row 0 inside the span for every kept cell) */
-    uint8_t *prev = buf0, *next = buf1;
-    memset(prev, 0, width + 32);
+static void fast_band(struct fast_job *j, int64_t d0, uint8_t *score) {
+    const int64_t n = (int64_t)j->n, d1 = d0 + FAST_BAND;
+    memset(score, 0, FAST_BAND + 32);
     const __m256i zero = _mm256_setzero_si256();
     const __m256i limit = _mm256_set1_epi16(255);
-    for (uint64_t p = 0; p < j->nrows; p++) {
+    for (int64_t p = 0; p < (int64_t)j->nrows; p++) {
+        int64_t lo = d0 > -p ? d0 : -p;                  /* column d + p >= 0 */
+        int64_t hi = d1 < n - p ? d1 : n - p;            /* column d + p < n */
+        if (lo >= hi) { if (d0 + p >= n) break; continue; }
+        const int8_t *scores = j->model + 4 * p;
         int32_t row_word;
-        memcpy(&row_word, j->model + 4 * p, 4);
-        const __m128i lut = _mm_set1_epi32(row_word);              /* bytes A,C,G,T repeated: pshufb index 0..3 */
-        next[0] = 0;
-        for (uint64_t s = 0; s < width; s += 16) {
-            const __m128i sy = _mm_loadu_si128((const __m128i *)(sym + s));
+        memcpy(&row_word, scores, 4);
+        const __m128i lut = _mm_set1_epi32(row_word);    /* bytes A,C,G,T repeated: pshufb index 0..3 */
+        const uint8_t *sym = j->symbols + p;             /* sym[d] is the symbol of column d + p */
+        int64_t d = lo;
+        for (; d + 16 <= hi; d += 16) {
+            uint8_t *cell = score + (d - d0);
+            const __m128i sy = _mm_loadu_si128((const __m128i *)(sym + d));
             const __m256i m = _mm256_cvtepi8_epi16(_mm_shuffle_epi8(lut, sy));
-            const __m256i old = _mm256_cvtepu8_epi16(_mm_loadu_si128((const __m128i *)(prev + s)));
+            const __m256i old = _mm256_cvtepu8_epi16(_mm_loadu_si128((const __m128i *)cell));
             __m256i t = _mm256_add_epi16(old, m);
             const __m256i hit = _mm256_cmpgt_epi16(t, limit);       /* t >= 256 */
             t = _mm256_andnot_si256(hit, _mm256_max_epi16(t, zero));
             const __m256i packed = _mm256_permute4x64_epi64(_mm256_packus_epi16(t, t), 0x08);
-            _mm_storeu_si128((__m128i *)(next + s + 1), _mm256_castsi256_si128(packed));
-            const unsigned mask = (unsigned)_mm256_movemask_epi8(hit);
-            if (mask) {
-                for (unsigned k = 0; k < 16; k++) {
-                    if (!(mask & (2u << (2 * k)))) continue;
-                    const uint64_t col = start + s + k;
-                    if (s + k < width && col >= a) {
-                        if (found < cap) hits[found] = havac_oracle_pack_hit((uint32_t)p, col);
-                        found++;
-                    }
-                }
+            _mm_storeu_si128((__m128i *)cell, _mm256_castsi256_si128(packed));
+            unsigned mask = (unsigned)_mm256_movemask_epi8(hit);
+            while (mask) {
+                const unsigned k = (unsigned)__builtin_ctz(mask) / 2;
+                mask &= ~(3u << (2 * k));
+                fast_emit(j, (uint64_t)p, (uint64_t)(d + k + p));
             }
         }
-        uint8_t *tmp = prev; prev = next; next = tmp;
+        for (; d < hi; d++) {                            /* ragged end of an edge band */
+            int t = (int)score[d - d0] + (int)scores[sym[d]];
+            uint8_t v = (uint8_t)t;
+            if (t < 0) v = 0;
+            if (t >= 256) { v = 0; fast_emit(j, (uint64_t)p, (uint64_t)(d + p)); }
+            score[d - d0] = v;
+        }
     }
-    return (int64_t)found;
 }
 
-__attribute__((target("avx2")))
 static void *fast_main(void *arg) {
     struct fast_job *j = (struct fast_job *)arg;
-    const uint64_t span = j->tile + j->nrows + 64;
-    uint8_t *buf0 = (uint8_t *)malloc(span + 64), *buf1 = (uint8_t *)malloc(span + 64);
-    if (!buf0 || !buf1) { free(buf0); free(buf1); j->found = -1; return NULL; }
-    uint64_t found = 0;
-    for (uint64_t t = j->tile_begin; t < j->tile_end; t++) {
-        uint64_t a = t * j->tile, b = a + j->tile;
-        if (b > j->n) b = j->n;
-        found = (uint64_t)fast_tile(j, a, b, buf0, buf1, j->hits, j->cap, found);
-    }
-    free(buf0); free(buf1);
-    j->found = (int64_t)found;
+    uint8_t *score = (uint8_t *)malloc(FAST_BAND + 64);
+    if (!score) { j->failed = 1; return NULL; }
+    const int64_t first = -((int64_t)j->nrows - 1);
+    for (uint64_t b = (uint64_t)j->thread; b < j->nbands && !j->failed; b += (uint64_t)j->nthreads)
+        fast_band(j, first + (int64_t)(b * FAST_BAND), score);
+    free(score);
+    if (!j->failed) qsort(j->keys, (size_t)j->count, sizeof(uint64_t), cmp_u64);
     return NULL;
 }
 
@@ -284,36 +291,39 @@ int64_t havac_oracle_ssv_fast(const uint8_t *symbols, uint64_t n, const int8_t *
     if (n == 0 || nrows == 0) return 0;
     if (nthreads <= 0) nthreads = (int)sysconf(_SC_NPROCESSORS_ONLN);
     if (nthreads < 1) nthreads = 1;
-    const uint64_t tile = fast_tile_width(nrows);
-    const uint64_t ntiles = (n + tile - 1) / tile;
-    if ((uint64_t)nthreads > ntiles) nthreads = (int)ntiles;
-    /* the symbol loads read up to 15 bytes past the span of the last tile: work on a padded copy */
+    const uint64_t nbands = (n + nrows - 1 + FAST_BAND - 1) / FAST_BAND;
+    if ((uint64_t)nthreads > nbands) nthreads = (int)nbands;
+    /* the 16-byte symbol loads of the last columns read past the end: work on a padded copy */
     uint8_t *padded = (uint8_t *)malloc((size_t)n + 64);
     struct fast_job *jobs = (struct fast_job *)calloc((size_t)nthreads, sizeof *jobs);
     pthread_t *tids = (pthread_t *)calloc((size_t)nthreads, sizeof *tids);
     if (!padded || !jobs || !tids) { free(padded); free(jobs); free(tids); return -1; }
     memcpy(padded, symbols, (size_t)n);
     memset(padded + n, 0, 64);
+    for (int t = 0; t < nthreads; t++)
+        jobs[t] = (struct fast_job){padded, n, model, nrows, nbands, t, nthreads, NULL, 0, 0, 0};
+    for (int t = 0; t < nthreads; t++) pthread_create(&tids[t], NULL, fast_main, &jobs[t]);
+    for (int t = 0; t < nthreads; t++) pthread_join(tids[t], NULL);
     int64_t total = 0;
     for (int t = 0; t < nthreads; t++) {
-        jobs[t] = (struct fast_job){padded, n, model, nrows, tile, ntiles * (uint64_t)t / (uint64_t)nthreads,
-                                    ntiles * (uint64_t)(t + 1) / (uint64_t)nthreads, NULL, cap, 0};
-        jobs[t].hits = (uint64_t *)malloc((size_t)(cap ? cap : 1) * sizeof(uint64_t));
-        if (!jobs[t].hits) total = -1;
+        if (jobs[t].failed) total = -1;
+        else if (total >= 0) total += (int64_t)jobs[t].count;
     }
-    if (total == 0) {
-        for (int t = 0; t < nthreads; t++) pthread_create(&tids[t], NULL, fast_main, &jobs[t]);
-        for (int t = 0; t < nthreads; t++) pthread_join(tids[t], NULL);
-        uint64_t stored = 0;
-        for (int t = 0; t < nthreads; t++) {
-            if (jobs[t].found < 0) { total = -1; break; }
-            uint64_t have = (uint64_t)jobs[t].found < cap ? (uint64_t)jobs[t].found : cap;
-            for (uint64_t i = 0; i < have && stored < cap; i++) hits[stored++] = jobs[t].hits[i];
-            total += jobs[t].found;
+    if (total >= 0) {
+        /* merge the sorted lists (keys are unique: one per cell); only the first `cap` records are stored */
+        uint64_t *at = (uint64_t *)calloc((size_t)nthreads, sizeof *at);
+        if (!at) total = -1;
+        for (uint64_t out = 0; total >= 0 && out < (uint64_t)total && out < cap; out++) {
+            int best = -1;
+            for (int t = 0; t < nthreads; t++)
+                if (at[t] < jobs[t].count && (best < 0 || jobs[t].keys[at[t]] < jobs[best].keys[at[best]])) best = t;
+            const uint64_t key = jobs[best].keys[at[best]++];
+            const uint64_t column = (key >> 38) * HAVAC_ORACLE_SEGMENT + (key & 0x3fffull);
+            hits[out] = havac_oracle_pack_hit((uint32_t)((key >> 14) & 0xffffffu), column);
         }
-        if (total >= 0) havac_oracle_sort_device_order(hits, stored);
+        free(at);
     }
-    for (int t = 0; t < nthreads; t++) free(jobs[t].hits);
+    for (int t = 0; t < nthreads; t++) free(jobs[t].keys);
     free(padded); free(jobs); free(tids);
     return total;
 }

@@ -76,8 +76,9 @@ int64_t havac_oracle_ssv_window(const uint8_t *symbols, uint64_t n, const int8_t
 int64_t havac_oracle_ssv_mt(const uint8_t *symbols, uint64_t n, const int8_t *model,
                             uint64_t nrows, uint64_t *hits, uint64_t cap, int nthreads);
 
-/* The same answer as havac_oracle_ssv_mt, computed with AVX2 (16 cells per instruction) on column tiles that
- * stay in the L1 cache, one pthread per run of tiles.  Falls back to havac_oracle_ssv_mt on a CPU without AVX2.
+/* The same answer as havac_oracle_ssv_mt, computed with AVX2 (16 cells per instruction) on bands of 16384
+ * diagonals whose scores stay in the L1 cache (a cell depends only on its own diagonal: no halo), bands dealt to
+ * pthreads.  Falls back to havac_oracle_ssv_mt on a CPU without AVX2.
  * A different route to the same numbers: tests/test_oracle.py checks it against havac_oracle_ssv and the
  * reference object; the GPU tests use it to compare WHOLE hit lists at BASELINE.json's full sizes. */
 int64_t havac_oracle_ssv_fast(const uint8_t *symbols, uint64_t n, const int8_t *model,

@@ -44,13 +44,13 @@ def check_windows(oracle, packed, model, got, windows):
         assert np.array_equal(oracle.device_order(mine), oracle.device_order(want)), (lo, hi, mine.size, want.size)
 
 
-def whole_list(oracle, packed, model, lo=0, hi=None):
+def whole_list(oracle, packed, model, lo=0, hi=None, cap=1 << 22):
     """Every record of columns [lo, hi) from the oracle's vectorised route (lo a multiple of 4)."""
     import os
     hi = packed.size * 4 if hi is None else hi
     start = max(0, lo - (model.shape[0] - 1)) // 4 * 4
     sym = synth.unpack_2bit(packed[start // 4: (hi + 3) // 4])[: hi - start]
-    recs = oracle.ssv_fast(sym, model, nthreads=min(16, os.cpu_count() or 1), cap=1 << 22)
+    recs = oracle.ssv_fast(sym, model, nthreads=min(16, os.cpu_count() or 1), cap=cap)
     rows, cols = oracle.unpack_hits(recs)
     keep = cols + np.uint64(start) >= np.uint64(lo)
     return oracle.device_order(oracle.pack_hits(rows[keep], cols[keep] + np.uint64(start)))
@@ -136,15 +136,28 @@ def test_c5_long_model_windows(torch_dev, oracle):
     assert np.array_equal(got, whole_list(oracle, packed, model))         # all 2.0e11 cells
 
 
-def test_c3_many_models_windows(torch_dev, oracle):
-    """Config C3 shape scaled to what the oracle can check: 120 concatenated models (~60k rows) x 1.2 Mbp."""
+def test_c3_full_size_whole_hit_list(torch_dev, oracle):
+    """Config C3 as BASELINE.json states it: 1000 models (lengths log-uniform in 50..2000, ~5e5 rows in all) x 10 Mbp,
+    one launch, ~5e12 cells: every record against the oracle's vectorised route."""
     torch, dev = torch_dev
-    lengths = synth.model_lengths(120)
-    model, cons = synth.model_collection(lengths, 2101)
-    n = 100 * synth.SEGMENT
+    model, cons = synth.model_collection(synth.model_lengths(1000), 2101)
+    n = 814 * synth.SEGMENT
     packed = synth.random_packed(n, 1303)
-    got = run_shards(torch, dev, packed, model, capacity=1 << 23)[0]
-    check_windows(oracle, packed, model, got, [(0, 1500), (n - 1500, n), (600_000, 601_500)])
+    got = run_shards(torch, dev, packed, model, capacity=1 << 27)[0]
+    assert got.size > 10_000_000
+    want = whole_list(oracle, packed, model, cap=got.size + 1024)
+    assert got.size == want.size and np.array_equal(got, want)
+
+
+def test_c5_full_size_whole_hit_list(torch_dev, oracle):
+    """Config C5 as BASELINE.json states it: one model of 20000 rows x 100 Mbp (2.0e12 cells), every record."""
+    torch, dev = torch_dev
+    model, cons = synth.dfam_like_model(20000, 2005)
+    packed = synth.random_packed(100_012_032, 1005)
+    got = run_shards(torch, dev, packed, model, capacity=1 << 26)[0]
+    assert got.size > 1_000_000
+    want = whole_list(oracle, packed, model, cap=got.size + 1024)
+    assert got.size == want.size and np.array_equal(got, want)
 
 
 def test_sort_hits_entry_point(torch_dev, oracle):
