@@ -180,7 +180,10 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % ndev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # HAVAC_BENCH_FORCE_DIST=1: rehearse the N > 1 code path (process group, gather, barrier, all-reduce) with the
+    # ranks there are, even one -- the only way to run it over RCCL on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("HAVAC_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -202,12 +205,12 @@ def main():
 
     hit_capacity = max(1 << 20, int(args.columns_per_gpu * nrows * 4e-5))
     depth = max(1, args.pipeline_depth)
-    engine = ShardedSsv(hit_capacity, device, depth=depth)
+    engine = ShardedSsv(hit_capacity, device, depth=depth, gather_when_alone=use_dist)
     my_cells = shard_cells(ncols, nrows, rank, world)
     total_cells = ncols * nrows
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -234,7 +237,7 @@ def main():
         merged = merged.clone()
     serial_ms, serial_timings = None, kernel_ms
     if depth > 1:       # the same steps strictly one after the other, for the record (not `value`)
-        serial = ShardedSsv(hit_capacity, device, depth=1)
+        serial = ShardedSsv(hit_capacity, device, depth=1, gather_when_alone=use_dist)
         run_steps(serial, 2)
         fence()
         t1 = time.perf_counter()
@@ -242,7 +245,7 @@ def main():
         fence()
         serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
         serial.close()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -299,7 +302,7 @@ def main():
             cores = min(16, len(os.sched_getaffinity(0)))   # a 1-GPU box's CPU share
             out["cpu_baseline"] = cpu_baseline(packed, model, hits_np, cores, args.cpu_cols_per_core)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

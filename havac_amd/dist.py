@@ -65,9 +65,12 @@ class ShardedSsv:
     kernels themselves are kept back to back, never side by side (pass k+1 waits for the kernel of pass k), so a
     kernel's event-timed duration stays the duration of that kernel alone."""
 
-    def __init__(self, hit_capacity: int, device: torch.device, depth: int = 1, back_to_back: bool = True):
+    def __init__(self, hit_capacity: int, device: torch.device, depth: int = 1, back_to_back: bool = True,
+                 gather_when_alone: bool = False):
         self.device = device
         self.back_to_back = back_to_back
+        # rehearsals on one GPU: run the collectives even in a one-rank group
+        self.gather_when_alone = gather_when_alone and dist.is_initialized()
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.slots = [_Slot(hit_capacity, device, depth > 1) for _ in range(max(1, depth))]
@@ -100,7 +103,7 @@ class ShardedSsv:
         slot = self.slots[self.in_flight.pop(0)]
         found = slot.ctx.finish()
         self.ctx, self.hits = slot.ctx, slot.hits
-        if self.world == 1:
+        if self.world == 1 and not self.gather_when_alone:
             return slot.hits[:found], found
         if slot.stream is None:
             merged, _ = gather_hits(slot.hits, found)

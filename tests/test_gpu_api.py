@@ -276,3 +276,39 @@ def test_native_software_testbench(tmp_path):
     out = subprocess.run([exe, "2", "3", "2000"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "ALL TESTS PASSED" in out.stdout and out.stdout.count("passed") >= 2
+
+
+def test_rccl_gather_of_hit_records_single_rank(oracle):
+    """The collectives of the N > 1 path on the real backend (nccl = RCCL), as far as one GPU allows: a one-rank
+    process group, gather_hits on device tensors issued from a side stream (what ShardedSsv does with passes in
+    flight), then the barrier and the MAX all-reduce bench.py uses."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from havac_amd.dist import gather_hits
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29533"
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        recs = oracle.pack_hits(np.arange(1000, dtype=np.uint64) % 77, np.arange(1000, dtype=np.uint64) * 13)
+        buf = torch.zeros(4096, dtype=torch.int64, device=dev)
+        buf[:1000] = torch.from_numpy(recs.view(np.int64)).to(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            merged, counts = gather_hits(buf, 1000)
+        side.synchronize()
+        assert counts == [1000]
+        assert np.array_equal(merged.cpu().numpy().view(np.uint64), recs)
+        empty, counts = gather_hits(buf, 0)
+        assert counts == [0] and empty.numel() == 0
+        dist.barrier()
+        t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == 1.5
+    finally:
+        dist.destroy_process_group()
