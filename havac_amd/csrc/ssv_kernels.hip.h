@@ -316,20 +316,9 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
     const int lane = threadIdx.x & 63;
     // readfirstlane: everything derived from the tile index is wave-uniform (SALU branches, scalar address math)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = tile_begin + blockIdx.x * kWavesPerBlock + wave;
-    if (tile >= tile_end) return;
     WaveLds* const lds = &wave_lds[wave];
     const HitSink sink{hits, hit_count, hit_capacity, lds, col_begin, col_end, row_bits};
     uint32_t staged = 0;          // wave-uniform
-
-    const int64_t d0 = first_diag + (int64_t)tile * kTileDiags;     // wave's first diagonal
-    const int64_t dl = d0 + lane * kDiagsPerLane;                   // lane's first diagonal
-    // steps whose cells of this tile can lie inside the matrix
-    int64_t p_lo = -d0 - kTileDiags;                                // first chunk touching column >= 0
-    if (p_lo < 0) p_lo = 0;
-    int64_t p_hi = col_end - d0;                                    // first chunk entirely right of the shard's columns
-    if (p_hi > (int64_t)nrows_padded) p_hi = nrows_padded;
-    if (p_lo >= p_hi) return;
 
     // LDS byte address of this wave's tables (a multiple of 128: code*8 is OR-ed into it)
     const uint32_t table_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds->table;
@@ -340,98 +329,126 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
     if (my_b == 0)        // the "outside the matrix" entry of each table never changes
         *(lds_words_out_t)(uintptr_t)(table_base + my_pair * kPairStride + kOutsideCode) = u32x2{kOutsideWord, kOutsideWord};
 
-    uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_pair)
+    const uint32_t tile = tile_begin + blockIdx.x * kWavesPerBlock + wave;
+    const int64_t d0 = first_diag + (int64_t)tile * kTileDiags;     // wave's first diagonal
+    const int64_t dl = d0 + lane * kDiagsPerLane;                   // lane's first diagonal
+    // steps whose cells of this tile can lie inside the matrix
+    int64_t p_lo = -d0 - kTileDiags;                                // first chunk touching column >= 0
+    if (p_lo < 0) p_lo = 0;
+    int64_t p_hi = col_end - d0;                                    // first chunk entirely right of the shard's columns
+    if (p_hi > (int64_t)nrows_padded) p_hi = nrows_padded;
+    // no early return: every wave of the block meets the others at the final flush
+    if (tile < tile_end && p_lo < p_hi) {
+        uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_pair)
 #pragma unroll
-    for (int i = 0; i < kRegs; i++) x[i] = x2[i] = kScoreZero;
+        for (int i = 0; i < kRegs; i++) x[i] = x2[i] = kScoreZero;
 
-    // Window of the current chunk, symbol positions [j, j+64) with j = dl + p0: C[k] is the LDS address of the
-    // table entry of the symbol pair (j+2k, j+2k+1).  The upper half of one chunk's window is the lower half of the
-    // next, so each chunk expands only the 32 new symbols.
-    uint32_t C[32];
-    // packed symbols [dl+rel, dl+rel+32) in x,y; in z the 16 separator bits of those symbol pairs (boundary mode);
-    // rel is wave-uniform
-    auto fetch_symbols = [&](int64_t rel) -> uint3 {
-        const bool edge = (d0 + rel < 0) || (d0 + rel + kTileDiags > nsymbols);   // the wave's 2048 positions
-        const int64_t pos = dl + rel;
-        const uint2 w = load_symbols(seq, nsymbols, pos, edge);
-        uint32_t separators = 0;
-        if (pair_mask && pos >= 0 && pos + 32 <= nsymbols) separators = pair_mask[pos >> 5];
-        return make_uint3(w.x, w.y, separators);
-    };
-    auto expand = [&](const uint3 packed, int64_t rel) {  // -> C[16 .. 32)
-        const bool edge = (d0 + rel < 0) || (d0 + rel + kTileDiags > nsymbols);
-        const int64_t pos = dl + rel;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t w = k < 8 ? packed.x : packed.y;
-            const int sh = (k & 7) * 4;                                  // the pair's 4 bits start here
-            const uint32_t code8 = sh == 0 ? (w << 3) : (w >> (sh - 3)); // code * 8 in bits [6:3]
-            C[16 + k] = (code8 & 0x78u) | table_base;
-        }
-        if (edge) {
-            // positions outside [0, N) use the entry that scores -1: pins the cell at 0, never hits
+        // Window of the current chunk, symbol positions [j, j+64) with j = dl + p0: C[k] is the LDS address of the
+        // table entry of the symbol pair (j+2k, j+2k+1).  The upper half of one chunk's window is the lower half of the
+        // next, so each chunk expands only the 32 new symbols.
+        uint32_t C[32];
+        // packed symbols [dl+rel, dl+rel+32) in x,y; in z the 16 separator bits of those symbol pairs (boundary mode);
+        // rel is wave-uniform
+        auto fetch_symbols = [&](int64_t rel) -> uint3 {
+            const bool edge = (d0 + rel < 0) || (d0 + rel + kTileDiags > nsymbols);   // the wave's 2048 positions
+            const int64_t pos = dl + rel;
+            const uint2 w = load_symbols(seq, nsymbols, pos, edge);
+            uint32_t separators = 0;
+            if (pair_mask && pos >= 0 && pos + 32 <= nsymbols) separators = pair_mask[pos >> 5];
+            return make_uint3(w.x, w.y, separators);
+        };
+        auto expand = [&](const uint3 packed, int64_t rel) {  // -> C[16 .. 32)
+            const bool edge = (d0 + rel < 0) || (d0 + rel + kTileDiags > nsymbols);
+            const int64_t pos = dl + rel;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const int64_t q = pos + 2 * k;     // q and q+1 are in or out together (pos, N even)
-                if (q < 0 || q >= nsymbols) C[16 + k] = table_base + kOutsideCode;
+                const uint32_t w = k < 8 ? packed.x : packed.y;
+                const int sh = (k & 7) * 4;                                  // the pair's 4 bits start here
+                const uint32_t code8 = sh == 0 ? (w << 3) : (w >> (sh - 3)); // code * 8 in bits [6:3]
+                C[16 + k] = (code8 & 0x78u) | table_base;
             }
-        }
-        if (pair_mask && __any(packed.z != 0)) {
-            // boundary mode: a separator pair scores -128 twice on every diagonal through it = a reset
+            if (edge) {
+                // positions outside [0, N) use the entry that scores -1: pins the cell at 0, never hits
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                if ((packed.z >> k) & 1u) C[16 + k] = table_base + kOutsideCode;
-        }
-    };
-    // A chunk's 16 step-pair tables: entry (a,b) of pair P = { word(step 2P, a), word(step 2P+1, b) } with
-    // word(t, a) = (M[t][a] << 8) | (M[t-1][a] << 24); rows[] is shifted by one, so rows[t] is M[t-1].
-    // Four lanes share a step pair: they fetch its three model rows and each writes the entries of one b.
-    struct ModelRows { uint32_t r0, r1, r2; };
-    auto fetch_rows = [&](int64_t p0) -> ModelRows {
-        const uint32_t* r = rows + p0 + 2 * my_pair;
-        return ModelRows{r[0], r[1], r[2]};
-    };
-    auto build_tables = [&](const ModelRows r) {
-        const uint32_t second = __builtin_amdgcn_perm(r.r1, r.r2, sel_second);
-        const lds_words_out_t out = (lds_words_out_t)(uintptr_t)my_entries_addr;
+                for (int k = 0; k < 16; k++) {
+                    const int64_t q = pos + 2 * k;     // q and q+1 are in or out together (pos, N even)
+                    if (q < 0 || q >= nsymbols) C[16 + k] = table_base + kOutsideCode;
+                }
+            }
+            if (pair_mask && __any(packed.z != 0)) {
+                // boundary mode: a separator pair scores -128 twice on every diagonal through it = a reset
 #pragma unroll
-        for (int a = 0; a < 4; a++) out[a] = u32x2{__builtin_amdgcn_perm(r.r0, r.r1, word_selector(a)), second};
-    };
-    expand(fetch_symbols(p_lo), p_lo);
-    // the global loads of a chunk are issued one chunk ahead, so their latency hides behind 16 step pairs
-    ModelRows next_rows = fetch_rows(p_lo);
-    uint3 next_symbols = fetch_symbols(p_lo + 32);
+                for (int k = 0; k < 16; k++)
+                    if ((packed.z >> k) & 1u) C[16 + k] = table_base + kOutsideCode;
+            }
+        };
+        // A chunk's 16 step-pair tables: entry (a,b) of pair P = { word(step 2P, a), word(step 2P+1, b) } with
+        // word(t, a) = (M[t][a] << 8) | (M[t-1][a] << 24); rows[] is shifted by one, so rows[t] is M[t-1].
+        // Four lanes share a step pair: they fetch its three model rows and each writes the entries of one b.
+        struct ModelRows { uint32_t r0, r1, r2; };
+        auto fetch_rows = [&](int64_t p0) -> ModelRows {
+            const uint32_t* r = rows + p0 + 2 * my_pair;
+            return ModelRows{r[0], r[1], r[2]};
+        };
+        auto build_tables = [&](const ModelRows r) {
+            const uint32_t second = __builtin_amdgcn_perm(r.r1, r.r2, sel_second);
+            const lds_words_out_t out = (lds_words_out_t)(uintptr_t)my_entries_addr;
+#pragma unroll
+            for (int a = 0; a < 4; a++) out[a] = u32x2{__builtin_amdgcn_perm(r.r0, r.r1, word_selector(a)), second};
+        };
+        expand(fetch_symbols(p_lo), p_lo);
+        // the global loads of a chunk are issued one chunk ahead, so their latency hides behind 16 step pairs
+        ModelRows next_rows = fetch_rows(p_lo);
+        uint3 next_symbols = fetch_symbols(p_lo + 32);
 
-    for (int64_t p0 = p_lo; p0 < p_hi; p0 += kChunkRows) {
-        // abort: a device word, read past the caches every 2048 rows (never on a wave's first chunk, so
-        // short models pay nothing)
-        if (abort_flag && ((p0 & 2047) == 0) && p0 != p_lo &&
-            __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
-        build_tables(next_rows);
-        // slide the window by 32 symbols
+        for (int64_t p0 = p_lo; p0 < p_hi; p0 += kChunkRows) {
+            // abort: a device word, read past the caches every 2048 rows (never on a wave's first chunk, so
+            // short models pay nothing)
+            if (abort_flag && ((p0 & 2047) == 0) && p0 != p_lo &&
+                __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+            build_tables(next_rows);
+            // slide the window by 32 symbols
 #pragma unroll
-        for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-        expand(next_symbols, p0 + 32);
-        next_rows = fetch_rows(p0 + kChunkRows);              // rows[] has kModelSlack words behind the model
-        next_symbols = fetch_symbols(p0 + kChunkRows + 32);
+            for (int k = 0; k < 16; k++) C[k] = C[k + 16];
+            expand(next_symbols, p0 + 32);
+            next_rows = fetch_rows(p0 + kChunkRows);              // rows[] has kModelSlack words behind the model
+            next_symbols = fetch_symbols(p0 + kChunkRows + 32);
 
-        uint32_t steps_with_hits = 0;   // wave-uniform
-        step_pairs<0>(x, x2, C, lds->masks, steps_with_hits, lane, std::make_integer_sequence<int, kChunkPairs / 2>{});
-        if (steps_with_hits) staged = drain_steps(sink, staged, steps_with_hits, (uint32_t)p0, d0, lane);
-        steps_with_hits = 0;
-        step_pairs<kChunkPairs / 2>(x, x2, C, lds->masks, steps_with_hits, lane, std::make_integer_sequence<int, kChunkPairs / 2>{});
-        if (steps_with_hits) staged = drain_steps(sink, staged, steps_with_hits, (uint32_t)p0 + kMaskSteps, d0, lane);
-    }
-    if (p_hi == (int64_t)nrows_padded) {
-        // the high cells run one row behind: one more step gives them the model's last row
-        build_tables(next_rows);                               // fetched for p_hi by the last chunk
+            uint32_t steps_with_hits = 0;   // wave-uniform
+            step_pairs<0>(x, x2, C, lds->masks, steps_with_hits, lane, std::make_integer_sequence<int, kChunkPairs / 2>{});
+            if (steps_with_hits) staged = drain_steps(sink, staged, steps_with_hits, (uint32_t)p0, d0, lane);
+            steps_with_hits = 0;
+            step_pairs<kChunkPairs / 2>(x, x2, C, lds->masks, steps_with_hits, lane, std::make_integer_sequence<int, kChunkPairs / 2>{});
+            if (steps_with_hits) staged = drain_steps(sink, staged, steps_with_hits, (uint32_t)p0 + kMaskSteps, d0, lane);
+        }
+        if (p_hi == (int64_t)nrows_padded) {
+            // the high cells run one row behind: one more step gives them the model's last row
+            build_tables(next_rows);                               // fetched for p_hi by the last chunk
 #pragma unroll
-        for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-        uint32_t steps_with_hits = 0;
-        step_pair<0>(x, x2, C, lds->masks, steps_with_hits, lane);
-        if (steps_with_hits) staged = drain_steps(sink, staged, steps_with_hits, (uint32_t)p_hi, d0, lane);
+            for (int k = 0; k < 16; k++) C[k] = C[k + 16];
+            uint32_t steps_with_hits = 0;
+            step_pair<0>(x, x2, C, lds->masks, steps_with_hits, lane);
+            if (steps_with_hits) staged = drain_steps(sink, staged, steps_with_hits, (uint32_t)p_hi, d0, lane);
+        }
+    }   // this wave's tile
+
+    // What is still staged goes out with ONE returning atomic per block, not per wave: the single counter word
+    // sustains ~90 returning atomics per microsecond chip-wide, and with one per wave every model shorter than ~200
+    // rows was bound by that rate, not by the VALU (48,836 tiles with a hit each = 0.55 ms on C2's 100 Mbp).
+    __shared__ uint32_t block_staged[kWavesPerBlock];
+    __shared__ unsigned long long block_base;
+    if (lane == 0) block_staged[wave] = staged;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < kWavesPerBlock; w++) total += block_staged[w];
+        block_base = total ? atomicAdd(hit_count, (unsigned long long)total) : 0ull;
     }
-    flush_hits(sink, staged, lane);
+    __syncthreads();
+    unsigned long long base = block_base;
+    for (uint32_t w = 0; w < wave; w++) base += block_staged[w];
+    for (uint32_t i = lane; i < staged; i += 64)
+        if (base + i < hit_capacity) hits[base + i] = lds->stage[i];
 }
 
 // ---------------------------------------------------------------------------
