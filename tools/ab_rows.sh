@@ -1,0 +1,11 @@
+#!/bin/bash
+# like tools/ab.sh, with the model-height sweep (tools/rows_probe.py) as the measurement -> gpurun_out/ab_rows.log
+set -e
+cd "$(dirname "$0")/.."
+: > gpurun_out/ab_rows.log
+for v in A B A B; do
+    cp build/ab/lib$v.so havac_amd/libhavac_dev.so
+    echo "== $v" >> gpurun_out/ab_rows.log
+    timeout -k 10 200 python tools/rows_probe.py 2>/dev/null >> gpurun_out/ab_rows.log
+done
+cat gpurun_out/ab_rows.log
