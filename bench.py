@@ -149,9 +149,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--columns-per-gpu", type=int, default=COLUMNS_PER_GPU)
-    ap.add_argument("--pipeline-depth", type=int, default=3,
+    ap.add_argument("--pipeline-depth", type=int, default=0,
                     help="passes in flight (own context, hit buffer and stream each): the ordering / gather of pass k "
-                         "overlaps the SSV kernel of pass k+1; the SSV kernels stay back to back.  1 = strictly serial")
+                         "overlaps the SSV kernel of pass k+1; the SSV kernels stay back to back.  1 = strictly serial; "
+                         "0 = 3 for passes up to 1e12 cells per GPU (C2 is 1e11), else 1: ordering tens of millions of "
+                         "records next to the following kernel slows that kernel by more than it hides "
+                         "(C3 shape: 303 vs 267 ms per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cols-per-core", type=int, default=500_000)
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -204,7 +207,7 @@ def main():
     d_phmm = torch.from_numpy(model.reshape(-1)).to(device)
 
     hit_capacity = max(1 << 20, int(args.columns_per_gpu * nrows * 4e-5))
-    depth = max(1, args.pipeline_depth)
+    depth = args.pipeline_depth if args.pipeline_depth > 0 else (3 if args.columns_per_gpu * nrows <= 1e12 else 1)
     engine = ShardedSsv(hit_capacity, device, depth=depth, gather_when_alone=use_dist)
     my_cells = shard_cells(ncols, nrows, rank, world)
     total_cells = ncols * nrows
@@ -227,6 +230,9 @@ def main():
             timings.append(engine.ctx.last_ms())
         return result, timings
 
+    # set-up, not warm-up: one pass through every slot so that each context has its sort buffers before anything is
+    # timed (a slot first used inside the timed region would pay a hipMalloc there when --warmup < --pipeline-depth)
+    run_steps(engine, depth)
     run_steps(engine, args.warmup)
     fence()
     t0 = time.perf_counter()
