@@ -43,11 +43,13 @@
 //    indexed statically in the fully unrolled chunk, so the slide is free.
 //  * HITS are rare (about 1e-5 per cell on Dfam-like models): after each step
 //    pair the 16 score registers are OR-ed and one wave-wide test looks at the
-//    low bytes; only then the slow path sorts out which step crossed, repairs
-//    the second step for cells that crossed on the first (they restart from 0,
-//    test/softSsv/SoftSsv.cpp:43-44), and parks one mask per step in LDS.
-//    Records leave through LDS staging with one atomic per burst and are put in
-//    the FPGA's order afterwards.
+//    low bytes; only then the slow path sorts out which step crossed, puts the
+//    crossed cells back to score 0 (0x7fff + 1 = 0x8000; test/softSsv/
+//    SoftSsv.cpp:43-44) -- taking the second step again for cells that crossed
+//    on the first -- and parks one mask per step in LDS.  Twice per chunk a
+//    scalar-unit routine turns masks into records in an LDS stage; records
+//    leave with one returning atomic per burst of 128 and one per block at the
+//    end of the tile, and are put in the FPGA's order afterwards.
 //
 // Roofline: integer VALU issue; HBM
 // traffic is N/4 + 4*rows + 8*hits bytes per launch, thousands of cells per byte.
