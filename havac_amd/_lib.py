@@ -29,6 +29,8 @@ SIGNATURES = {
     "havac_dev_write_sequence": (C.c_int, [_vp, _u8p, C.c_uint64]),
     "havac_dev_write_phmm": (C.c_int, [_vp, _i8p, C.c_uint64]),
     "havac_dev_write_separator_mask": (C.c_int, [_vp, _u8p, C.c_uint64]),
+    "havac_dev_write_sequence_chars": (C.c_int, [_vp, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "havac_dev_read_sequence": (C.c_int, [_vp, C.c_void_p, C.c_uint64]),
     "havac_dev_run_async": (C.c_int, [_vp]),
     "havac_dev_state": (C.c_int, [_vp]),
     "havac_dev_wait": (C.c_int, [_vp, C.c_uint32]),

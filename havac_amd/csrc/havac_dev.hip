@@ -8,6 +8,7 @@
 // HAVAC_E_NO_DEVICE / HAVAC_E_RUNTIME.
 #include "../../include/havac_dev.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -325,6 +326,10 @@ struct DevicePart {
     hipStream_t abort_stream = nullptr; // abort() writes the word from here while the kernel runs
     hipEvent_t done = nullptr;
     uint64_t found = 0;
+    // text staging of havac_dev_write_sequence_chars (allocated on first use)
+    char* d_chars[2] = {nullptr, nullptr};
+    hipEvent_t chars_copied[2] = {nullptr, nullptr}, chars_packed[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
 };
 
 struct havac_dev {
@@ -395,6 +400,12 @@ extern "C" void havac_dev_destroy(havac_dev* d) {
         if (p.d_mask) (void)hipFree(p.d_mask);
         if (p.d_hits) (void)hipFree(p.d_hits);
         if (p.d_abort) (void)hipFree(p.d_abort);
+        for (int k = 0; k < 2; k++) {
+            if (p.d_chars[k]) (void)hipFree(p.d_chars[k]);
+            if (p.chars_copied[k]) (void)hipEventDestroy(p.chars_copied[k]);
+            if (p.chars_packed[k]) (void)hipEventDestroy(p.chars_packed[k]);
+        }
+        if (p.copy_stream) (void)hipStreamDestroy(p.copy_stream);
         if (p.abort_stream) (void)hipStreamDestroy(p.abort_stream);
         if (p.done) (void)hipEventDestroy(p.done);
         if (p.stream) (void)hipStreamDestroy(p.stream);
@@ -449,6 +460,102 @@ extern "C" int havac_dev_write_sequence(havac_dev* d, const uint8_t* packed, uin
     d->mask_bytes = 0;                       // a new sequence has no separators until a mask is written for it
     if (nbytes == 0) return HAVAC_OK;
     return upload(d, &DevicePart::d_seq, &DevicePart::seq_alloc, packed, nbytes);
+}
+
+// SURVEY.md section 8 row f4.  Text in, packed on the GPU.  Per GPU: two staging buffers of kCharChunk characters;
+// chunk c is copied on the copy stream while the pack kernel of chunk c-1 runs on the compute stream, and a
+// staging buffer is reused only after the kernel that read it has finished.
+static const uint64_t kCharChunk = 32ull << 20;
+
+extern "C" int havac_dev_write_sequence_chars(havac_dev* d, const char* chars, uint64_t nchars, const uint64_t* patch_columns,
+                                              const uint8_t* patch_symbols, uint64_t npatches) {
+    if (!d || (!chars && nchars) || (npatches && (!patch_columns || !patch_symbols))) return HAVAC_E_ARGUMENT;
+    const uint64_t ncolumns = (nchars + HAVAC_SEGMENT_COLUMNS - 1) / HAVAC_SEGMENT_COLUMNS * HAVAC_SEGMENT_COLUMNS;
+    const uint64_t nbytes = ncolumns / 4;
+    if (nbytes >= (4ull << 30)) {
+        d->err = "compressed sequence size must be less than 4GiB. length requested: " + std::to_string(nbytes) + " bytes.";
+        return HAVAC_E_LENGTH;
+    }
+    for (uint64_t i = 0; i < npatches; i++)
+        if (patch_columns[i] >= ncolumns || (i && patch_columns[i] <= patch_columns[i - 1])) {
+            d->err = "patch columns must be ascending and inside the padded sequence";
+            return HAVAC_E_ARGUMENT;
+        }
+    d->seq_bytes = nbytes;
+    d->mask_bytes = 0;
+    if (nbytes == 0) return HAVAC_OK;
+    // page-locked source: the chunk copies then run at PCIe speed and truly asynchronously; if the pages cannot be
+    // locked the copies still work, through the runtime's own staging
+    const bool locked = hipHostRegister(const_cast<char*>(chars), nchars, hipHostRegisterDefault) == hipSuccess;
+    if (!locked) (void)hipGetLastError();
+    int rc = HAVAC_OK;
+    auto run = [&]() -> int {
+        for (DevicePart& p : d->parts) {
+            HIP_TRY(d->err, hipSetDevice(p.device));
+            if (p.seq_alloc < nbytes) {
+                if (p.d_seq) (void)hipFree(p.d_seq);
+                p.d_seq = nullptr; p.seq_alloc = 0;
+                HIP_TRY(d->err, hipMalloc(&p.d_seq, nbytes));
+                p.seq_alloc = nbytes;
+            }
+            if (!p.d_chars[0]) {
+                for (int k = 0; k < 2; k++) {
+                    HIP_TRY(d->err, hipMalloc(&p.d_chars[k], kCharChunk));
+                    HIP_TRY(d->err, hipEventCreateWithFlags(&p.chars_copied[k], hipEventDisableTiming));
+                    HIP_TRY(d->err, hipEventCreateWithFlags(&p.chars_packed[k], hipEventDisableTiming));
+                }
+                HIP_TRY(d->err, hipStreamCreateWithFlags(&p.copy_stream, hipStreamNonBlocking));
+            }
+            uint32_t* const packed = reinterpret_cast<uint32_t*>(p.d_seq);
+            uint64_t chunk = 0;
+            for (uint64_t off = 0; off < ncolumns; off += kCharChunk, chunk++) {
+                const int k = (int)(chunk & 1);
+                const uint64_t have = off < nchars ? std::min(kCharChunk, nchars - off) : 0;     // characters in this chunk
+                const uint64_t upto = std::min(off + kCharChunk, ncolumns);                      // columns it covers
+                if (chunk >= 2) HIP_TRY(d->err, hipStreamWaitEvent(p.copy_stream, p.chars_packed[k], 0));
+                if (have) HIP_TRY(d->err, hipMemcpyAsync(p.d_chars[k], chars + off, have, hipMemcpyHostToDevice, p.copy_stream));
+                HIP_TRY(d->err, hipEventRecord(p.chars_copied[k], p.copy_stream));
+                HIP_TRY(d->err, hipStreamWaitEvent(p.stream, p.chars_copied[k], 0));
+                const uint64_t words = (upto - off) / 16;
+                hipLaunchKernelGGL(ssv_pack_chars, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, p.stream,
+                                   reinterpret_cast<const uint8_t*>(p.d_chars[k]), off, nchars, upto, packed);
+                HIP_TRY(d->err, hipEventRecord(p.chars_packed[k], p.stream));
+            }
+            if (npatches) {
+                uint64_t* d_cols = nullptr; uint8_t* d_syms = nullptr;
+                HIP_TRY(d->err, hipMalloc(&d_cols, npatches * sizeof(uint64_t)));
+                if (hipMalloc(&d_syms, npatches) != hipSuccess) { (void)hipFree(d_cols); d->err = "out of device memory"; return HAVAC_E_NOMEM; }
+                hipError_t e = hipMemcpyAsync(d_cols, patch_columns, npatches * sizeof(uint64_t), hipMemcpyHostToDevice, p.stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(d_syms, patch_symbols, npatches, hipMemcpyHostToDevice, p.stream);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(ssv_patch_symbols, dim3((unsigned)((npatches + 255) / 256)), dim3(256), 0, p.stream,
+                                       d_cols, d_syms, npatches, packed);
+                    e = hipStreamSynchronize(p.stream);
+                }
+                (void)hipFree(d_cols); (void)hipFree(d_syms);
+                if (e != hipSuccess) { d->err = hip_msg("patching the sequence", e); return HAVAC_E_RUNTIME; }
+            }
+        }
+        for (DevicePart& p : d->parts) {
+            HIP_TRY(d->err, hipSetDevice(p.device));
+            HIP_TRY(d->err, hipStreamSynchronize(p.stream));
+            HIP_TRY(d->err, hipGetLastError());
+        }
+        return HAVAC_OK;
+    };
+    rc = run();
+    if (locked) (void)hipHostUnregister(const_cast<char*>(chars));
+    return rc;
+}
+
+extern "C" int havac_dev_read_sequence(havac_dev* d, uint8_t* out, uint64_t nbytes) {
+    if (!d || (!out && nbytes)) return HAVAC_E_ARGUMENT;
+    if (nbytes > d->seq_bytes) { d->err = "the device holds fewer sequence bytes than requested"; return HAVAC_E_LENGTH; }
+    if (nbytes == 0) return HAVAC_OK;
+    DevicePart& p = d->parts[0];
+    HIP_TRY(d->err, hipSetDevice(p.device));
+    HIP_TRY(d->err, hipMemcpy(out, p.d_seq, nbytes, hipMemcpyDeviceToHost));
+    return HAVAC_OK;
 }
 
 extern "C" int havac_dev_write_separator_mask(havac_dev* d, const uint8_t* pair_bitmap, uint64_t nbytes) {

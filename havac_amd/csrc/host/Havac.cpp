@@ -79,6 +79,17 @@ void Havac::loadSequence(const std::string fastaSrc) {
     if (rc == FASTA_VECTOR_ALLOCATION_FAIL) throw std::bad_alloc();
     if (rc == FASTA_VECTOR_FILE_OPEN_FAIL) throw std::runtime_error("Could not open fasta file for reading.");
     if (rc == FASTA_VECTOR_FILE_READ_FAIL) throw std::runtime_error("Error while reading from the opened fasta file.");
+    if (devicePacking_ && !boundaryMode_ && !bothStrands_) {
+        // the text goes to the GPU in chunks and is packed there; the host only looks for the
+        // characters that are not a/c/g/t and draws their symbols (same rand() order as SequencePreprocessor)
+        vector<uint64_t> patchColumns;
+        vector<uint8_t> patchSymbols;
+        SequencePreprocessor::collectPatches(fastaVector, patchColumns, patchSymbols);
+        check(havac_dev_write_sequence_chars(dev_, fastaVector->sequence.charData, fastaVector->sequence.count,
+                                             patchColumns.data(), patchSymbols.data(), patchColumns.size()));
+        sequenceLoadedToDevice = true;
+        return;
+    }
     SequencePreprocessor preprocessor(fastaVector, boundaryMode_);
     if (bothStrands_) {
         vector<uint64_t> starts, residues;
@@ -128,6 +139,11 @@ void Havac::setBoundaryMode(bool on) {
     if (phmmLoadedToDevice || sequenceLoadedToDevice)
         throw std::logic_error("setBoundaryMode must be called before loadPhmm and loadSequence.");
     boundaryMode_ = on;
+}
+
+void Havac::setDevicePacking(bool on) {
+    if (sequenceLoadedToDevice) throw std::logic_error("setDevicePacking must be called before loadSequence.");
+    devicePacking_ = on;
 }
 
 void Havac::setBothStrands(bool on) {

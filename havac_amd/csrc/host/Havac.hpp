@@ -96,6 +96,10 @@ public:
     void setBothStrands(bool on);
     // Hits of the finished run merged into windows (see HavacWindow); `flank` residues are added on both sides.
     vector<HavacWindow> getWindowsFromFinishedRun(uint32_t flank = 0);
+    // Packing on the GPU, on by default in the plain mode: loadSequence sends the text
+    // and the symbols it drew for the non-a/c/g/t columns; the device buffer is byte for byte what the host packer
+    // (SequencePreprocessor) would have produced with the same rand() state.  Off = pack on the host.
+    void setDevicePacking(bool on);
     void setHitCapacity(uint64_t maxHits);                 // the reference's buffer is a fixed 3.5 GiB
     void lastRunMilliseconds(float *ssvKernelMs, float *totalMs);
     const vector<uint64_t> &rawHitsOfLastFetch() const { return rawHits_; }
@@ -116,6 +120,7 @@ private:
     vector<uint64_t> rawHits_;
     bool boundaryMode_ = false;
     bool bothStrands_ = false;
+    bool devicePacking_ = true;
     uint64_t forwardColumns_ = 0;                          // both strands: columns of the forward half
     vector<uint64_t> residueCounts_;                       // both strands: residues per record
     vector<uint64_t> recordStarts_, recordLengths_;        // boundary mode: global column of each record

@@ -14,6 +14,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace {
 constexpr uint32_t kSegment = 12288;   // NUM_CELL_PROCESSORS, device/PublicDefines.h:18-22
@@ -122,6 +125,55 @@ uint64_t SequencePreprocessor::appendReverseStrand(const std::vector<uint64_t> &
     }
     symbols_ *= 2; segments_ *= 2; bytes_ *= 2;
     return nf;
+}
+
+namespace {
+// index of the first character at or after `from` that is not a/c/g/t (either case), or `count`
+#if defined(__x86_64__)
+__attribute__((target("avx2")))
+uint64_t nextOtherAvx2(const unsigned char *chars, uint64_t from, uint64_t count) {
+    const __m256i fold = _mm256_set1_epi8(0x20);
+    const __m256i a = _mm256_set1_epi8('a'), c = _mm256_set1_epi8('c'), g = _mm256_set1_epi8('g'), t = _mm256_set1_epi8('t');
+    uint64_t i = from;
+    for (; i + 32 <= count; i += 32) {
+        const __m256i x = _mm256_or_si256(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(chars + i)), fold);
+        const __m256i plain = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(x, a), _mm256_cmpeq_epi8(x, c)),
+                                              _mm256_or_si256(_mm256_cmpeq_epi8(x, g), _mm256_cmpeq_epi8(x, t)));
+        const uint32_t other = ~(uint32_t)_mm256_movemask_epi8(plain);   // x | 0x20 == 'a' only for 'A' and 'a', etc.
+        if (other) return i + (uint64_t)__builtin_ctz(other);
+    }
+    for (; i < count; i++)
+        if (kCodes.code[chars[i]] > 3) return i;
+    return count;
+}
+#endif
+uint64_t nextOther(const unsigned char *chars, uint64_t from, uint64_t count) {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2")) return nextOtherAvx2(chars, from, count);
+#endif
+    for (uint64_t i = from; i < count; i++)
+        if (kCodes.code[chars[i]] > 3) return i;
+    return count;
+}
+}  // namespace
+
+void SequencePreprocessor::collectPatches(const FastaVector *fastaVector, std::vector<uint64_t> &columns,
+                                          std::vector<uint8_t> &symbols) {
+    const unsigned char *chars = reinterpret_cast<const unsigned char *>(fastaVector->sequence.charData);
+    const uint64_t count = fastaVector->sequence.count;
+    columns.clear();
+    symbols.clear();
+    for (uint64_t i = nextOther(chars, 0, count); i < count; i = nextOther(chars, i + 1, count)) {
+        const uint8_t code = getCompressedSymbol((char)chars[i]);
+        columns.push_back(i);
+        symbols.push_back((uint8_t)(code & 3u));
+        // 'Y' drew 1: the reference ORs 4 << shift into the byte, i.e. sets the low bit of the next symbol of the same
+        // byte; every later symbol clears its own field before writing, so the bit survives only behind the last character
+        if (code == 4 && i + 1 == count && (i % 4) != 3) {
+            columns.push_back(i + 1);
+            symbols.push_back(1);
+        }
+    }
 }
 
 uint8_t SequencePreprocessor::getCompressedSymbol(const char c) {

@@ -37,6 +37,14 @@ public:
     // One character to its 2-bit code (may return 4 for 'Y'/'y': the reference's precedence slip).
     static uint8_t getCompressedSymbol(char originalSymbol);
 
+    // For packing on the GPU (include/havac_dev.h: havac_dev_write_sequence_chars): the
+    // columns that are not a/c/g/t and the symbol each of them gets -- getCompressedSymbol called for exactly those
+    // characters, in order, so rand() is drawn as often and in the same order as by the constructor above, and the
+    // device buffer equals getCompressedSequenceBuffer() byte for byte (the 'Y' spill included: a final 'Y' that
+    // draws 1 sets the low bit of the first padding column).
+    static void collectPatches(const struct FastaVector *fastaVector, std::vector<uint64_t> &columns,
+                               std::vector<uint8_t> &symbols);
+
 private:
     uint32_t originalLength_ = 0, segments_ = 0, symbols_ = 0, bytes_ = 0;
     std::vector<uint8_t> packed_;

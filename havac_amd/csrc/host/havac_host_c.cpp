@@ -91,6 +91,7 @@ int havac_host_get_hit_strands(havac_host *h, uint8_t *reverse, uint32_t cap, ui
     for (uint32_t i = 0; i < cap && i < h->hits.size(); i++) reverse[i] = h->hits[i].reverseStrand ? 1 : 0;
     return HAVAC_OK;
 }
+int havac_host_set_device_packing(havac_host *h, int on) { return guarded(h, [&] { h->obj->setDevicePacking(on != 0); }); }
 int havac_host_set_boundary_mode(havac_host *h, int on) { return guarded(h, [&] { h->obj->setBoundaryMode(on != 0); }); }
 
 int havac_host_state(havac_host *h) {
@@ -175,6 +176,27 @@ int havac_host_pack_fasta(const char *path, int64_t seed, uint8_t *out, uint64_t
     if (nchars) *nchars = fv.sequence.count;
     if (nrecords) *nrecords = (uint32_t)fv.metadata.count;
     if (out && cap >= packed.size()) std::memcpy(out, packed.data(), packed.size());
+    fastaVectorDealloc(&fv);
+    return HAVAC_OK;
+}
+
+int havac_host_text_and_patches(const char *path, int64_t seed, char *chars, uint64_t charsCap, uint64_t *nchars,
+                                uint64_t *patchColumns, uint8_t *patchSymbols, uint64_t patchCap, uint64_t *npatches) {
+    FastaVector fv;
+    if (fastaVectorInit(&fv) != FASTA_VECTOR_OK) return HAVAC_E_NOMEM;
+    FastaVectorReturnCode rc = fastaVectorReadFasta(path, &fv);
+    if (rc != FASTA_VECTOR_OK) { fastaVectorDealloc(&fv); return rc == FASTA_VECTOR_ALLOCATION_FAIL ? HAVAC_E_NOMEM : HAVAC_E_RUNTIME; }
+    if (seed >= 0) std::srand((unsigned)seed);
+    vector<uint64_t> columns;
+    vector<uint8_t> symbols;
+    SequencePreprocessor::collectPatches(&fv, columns, symbols);
+    if (nchars) *nchars = fv.sequence.count;
+    if (npatches) *npatches = columns.size();
+    if (chars && charsCap >= fv.sequence.count) std::memcpy(chars, fv.sequence.charData, fv.sequence.count);
+    if (patchColumns && patchSymbols && patchCap >= columns.size()) {
+        std::memcpy(patchColumns, columns.data(), columns.size() * sizeof(uint64_t));
+        std::memcpy(patchSymbols, symbols.data(), symbols.size());
+    }
     fastaVectorDealloc(&fv);
     return HAVAC_OK;
 }

@@ -115,6 +115,51 @@ __global__ void ssv_pad_model(const int8_t* __restrict__ phmm, uint32_t nrows,
 }
 
 // ---------------------------------------------------------------------------
+// Text -> 2-bit symbols.  One thread packs 16 characters into one 32-bit word with
+// the layout of host/sequence/SequencePreprocessor.cpp:46-57 (symbol i in byte i/4, bits (i%4)*2).  For a/c/g/t in
+// either case the code is a function of bits 1..2 of the character: A 0x41, C 0x43, G 0x47, T 0x54 give
+// (c >> 1) & 3 = 0, 1, 3, 2, and x ^ (x >> 1) turns that into 0, 1, 2, 3.  Other characters produce some value
+// here and are overwritten by ssv_patch_symbols.  `chars` starts at column `first_column` (a multiple of 16);
+// columns at or beyond `nchars` are symbol 0 (the reference's zero padding, :41).
+__global__ void ssv_pack_chars(const uint8_t* __restrict__ chars, uint64_t first_column, uint64_t nchars,
+                               uint64_t ncolumns, uint32_t* __restrict__ packed) {
+    const uint64_t word = first_column / 16 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t column = word * 16;
+    if (column >= ncolumns) return;
+    uint32_t out = 0;
+    if (column + 16 <= nchars) {
+        const uint4 v = *reinterpret_cast<const uint4*>(chars + (column - first_column));
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t t = (w[k] >> 1) & 0x03030303u;          // per character: 0, 1, 3, 2 for A, C, G, T
+            t ^= (t >> 1) & 0x01010101u;                      // -> 0, 1, 2, 3
+            const uint32_t byte = (t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xffu;
+            out |= byte << (8 * k);
+        }
+    } else {
+        for (int i = 0; i < 16; i++) {
+            if (column + i >= nchars) break;
+            uint32_t t = (chars[column - first_column + i] >> 1) & 3u;
+            t ^= t >> 1;
+            out |= t << (2 * i);
+        }
+    }
+    packed[word] = out;
+}
+
+// columns that are not a/c/g/t: the symbol the host drew for them
+__global__ void ssv_patch_symbols(const uint64_t* __restrict__ columns, const uint8_t* __restrict__ symbols,
+                                  uint64_t npatches, uint32_t* __restrict__ packed) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npatches) return;
+    const uint64_t column = columns[i];
+    const uint32_t shift = (uint32_t)(column % 16) * 2;
+    atomicAnd(&packed[column / 16], ~(3u << shift));
+    atomicOr(&packed[column / 16], (uint32_t)(symbols[i] & 3u) << shift);
+}
+
+// ---------------------------------------------------------------------------
 typedef short short2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) u32x2* lds_words_t;

@@ -34,6 +34,9 @@ HOST_SIGNATURES = {
     "havac_host_set_hit_capacity": (C.c_int, [_vp, C.c_uint64]),
     "havac_host_set_boundary_mode": (C.c_int, [_vp, C.c_int]),
     "havac_host_set_both_strands": (C.c_int, [_vp, C.c_int]),
+    "havac_host_set_device_packing": (C.c_int, [_vp, C.c_int]),
+    "havac_host_text_and_patches": (C.c_int, [C.c_char_p, C.c_int64, _vp, C.c_uint64, C.POINTER(C.c_uint64), _vp, _vp,
+                                              C.c_uint64, C.POINTER(C.c_uint64)]),
     "havac_host_get_hit_strands": (C.c_int, [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "havac_host_get_hits": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "havac_host_get_raw_hits": (C.c_int, [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
@@ -143,6 +146,10 @@ class Havac:
         """Not in the reference: also score the reverse complement of every record (nhmmer's default)."""
         self._check(self._L.havac_host_set_both_strands(self._h, int(bool(on))))
 
+    def setDevicePacking(self, on: bool):
+        """Not in the reference: pack the text on the GPU (default) or on the host."""
+        self._check(self._L.havac_host_set_device_packing(self._h, int(bool(on))))
+
     def setHitCapacity(self, n: int):
         self._check(self._L.havac_host_set_hit_capacity(self._h, n))
 
@@ -215,6 +222,24 @@ def pack_fasta(path: str, seed: int = -1):
     if rc != 0:
         raise_for(rc, f"could not read {path}")
     return out, nc.value, nr.value
+
+
+def text_and_patches(path: str, seed: int = -1):
+    """What loadSequence sends to the GPU when it packs there -> (chars uint8, patch columns uint64, patch symbols uint8)."""
+    L = load_host()
+    nc, npatch = C.c_uint64(0), C.c_uint64(0)
+    rc = L.havac_host_text_and_patches(os.fsencode(path), -1, None, 0, C.byref(nc), None, None, 0, C.byref(npatch))
+    if rc != 0:
+        raise_for(rc, f"could not read {path}")
+    # the counting call above drew from rand() as well: the caller's seed is applied by the second call
+    chars = np.empty(nc.value, np.uint8)
+    cols = np.empty(npatch.value, np.uint64)
+    syms = np.empty(npatch.value, np.uint8)
+    rc = L.havac_host_text_and_patches(os.fsencode(path), seed, chars.ctypes.data, chars.size, C.byref(nc),
+                                       cols.ctypes.data, syms.ctypes.data, cols.size, C.byref(npatch))
+    if rc != 0:
+        raise_for(rc, f"could not read {path}")
+    return chars, cols, syms
 
 
 def project_hmm(path: str, p_value: float = 0.02):

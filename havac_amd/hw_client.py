@@ -86,6 +86,25 @@ class HavacHwClient:
         buf = np.ascontiguousarray(compressedSequence, dtype=np.uint8)
         self._check(self._L.havac_dev_write_sequence(self._h, buf.ctypes.data, buf.size))
 
+    def writeSequenceChars(self, chars, patchColumns=(), patchSymbols=()):
+        """Not in the reference: the sequence as text, one byte per column, packed on the
+        GPU; `patchColumns` (ascending) / `patchSymbols` (0..3) give the columns that are not a/c/g/t."""
+        buf = np.ascontiguousarray(np.frombuffer(chars, dtype=np.uint8) if isinstance(chars, (bytes, bytearray)) else chars,
+                                   dtype=np.uint8)
+        cols = np.ascontiguousarray(patchColumns, dtype=np.uint64)
+        syms = np.ascontiguousarray(patchSymbols, dtype=np.uint8)
+        if cols.size != syms.size:
+            raise ValueError("one symbol per patch column")
+        self._check(self._L.havac_dev_write_sequence_chars(self._h, buf.ctypes.data if buf.size else None, buf.size,
+                                                           cols.ctypes.data if cols.size else None,
+                                                           syms.ctypes.data if syms.size else None, cols.size))
+
+    def readSequence(self, nbytes: int) -> np.ndarray:
+        """The packed sequence as it stands in HBM (checking aid, not in the reference)."""
+        out = np.empty(int(nbytes), np.uint8)
+        self._check(self._L.havac_dev_read_sequence(self._h, out.ctypes.data if out.size else None, out.size))
+        return out
+
     def writeSeparatorMask(self, pairBitmap):
         """Boundary mode (not in the reference): one bit per aligned symbol pair; None or empty removes the mask."""
         buf = np.ascontiguousarray(pairBitmap if pairBitmap is not None else [], dtype=np.uint8)

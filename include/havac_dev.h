@@ -105,6 +105,20 @@ int havac_dev_set_hit_capacity(havac_dev *dev, uint64_t max_hits);
  * Borrowed host pointer, copied to HBM before return. */
 int havac_dev_write_sequence(havac_dev *dev, const uint8_t *packed2bit, uint64_t nbytes);
 
+/* Optional, not in the reference (packing on the GPU, pipelined host-to-device copy).
+ * The sequence as TEXT: `chars` holds nchars bytes, one per column -- the FASTA residues with the '\0' that ends
+ * every record, exactly what host/sequence/SequencePreprocessor.cpp:9-59 packs.  a/c/g/t (either case) are packed
+ * to 2 bits on the GPU, chunk by chunk while later chunks are still crossing PCIe; every other column is listed in
+ * `patch_columns` (ascending) with the symbol 0..3 the host drew for it in the reference's rand() order
+ * (SequencePreprocessor.cpp:61-84), and is patched in afterwards.  Columns from nchars up to the next multiple of
+ * 12288 are symbol 0, as the reference pads.  The device buffer ends up byte for byte what
+ * havac_dev_write_sequence would have stored for the host-packed sequence. */
+int havac_dev_write_sequence_chars(havac_dev *dev, const char *chars, uint64_t nchars, const uint64_t *patch_columns,
+                                   const uint8_t *patch_symbols, uint64_t npatches);
+
+/* The packed sequence as it stands in HBM (first GPU of the handle): for checking the entry point above. */
+int havac_dev_read_sequence(havac_dev *dev, uint8_t *packed2bit, uint64_t nbytes);
+
 /* Optional, not in the reference ("boundary mode").  One bit per aligned symbol
  * pair (bit k of byte j = symbols 16j+2k, 16j+2k+1) of the sequence written before it; a set bit makes both
  * symbols score -128 on every model row, which resets every diagonal that crosses the pair (255-128-128 < 0)

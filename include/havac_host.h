@@ -36,6 +36,8 @@ int havac_host_set_hit_capacity(havac_host *h, uint64_t max_hits);
 int havac_host_set_boundary_mode(havac_host *h, int on);
 /* Havac::setBothStrands (not in the reference): also score every record's reverse complement; before loadSequence */
 int havac_host_set_both_strands(havac_host *h, int on);
+/* Havac::setDevicePacking (not in the reference; on by default): pack the text on the GPU; before loadSequence */
+int havac_host_set_device_packing(havac_host *h, int on);
 /* reverseStrand flag of the hits of the last havac_host_get_hits call, one byte each */
 int havac_host_get_hit_strands(havac_host *h, uint8_t *reverse, uint32_t cap, uint32_t *count);
 /* Havac::getHitsFromFinishedRun :145-187.  First call with cap = 0 to learn the count. */
@@ -67,6 +69,12 @@ float havac_host_project_score(float emission_score, float multiplier);
 int havac_host_resolve_hits(const char *fasta_path, const char *hmm_path, const uint64_t *raw, uint32_t nraw,
                             uint64_t *sequence_position, uint32_t *sequence_index, uint32_t *phmm_position,
                             uint32_t *phmm_index, uint32_t cap, uint32_t *count);
+
+/* What loadSequence sends to the GPU when it packs there: the file's characters (records + terminators; nchars) and
+ * the columns that are not a/c/g/t with the symbols drawn for them (SequencePreprocessor::collectPatches); seed as
+ * in havac_host_pack_fasta.  Writes at most `cap` characters / patches; *nchars, *npatches = the full counts. */
+int havac_host_text_and_patches(const char *fasta_path, int64_t seed, char *chars, uint64_t chars_cap, uint64_t *nchars,
+                                uint64_t *patch_columns, uint8_t *patch_symbols, uint64_t patch_cap, uint64_t *npatches);
 
 /* Hits -> merged windows (Havac.hpp: havacMergeHitsToWindows).  `reverse_strand` may
  * be NULL (all forward).  Writes at most `cap` windows into the seven output arrays, *count = windows found. */

@@ -312,3 +312,64 @@ def test_rccl_gather_of_hit_records_single_rank(oracle):
         assert float(t.item()) == 1.5
     finally:
         dist.destroy_process_group()
+
+
+def test_sequence_packed_on_the_gpu(oracle):
+    """havac_dev_write_sequence_chars: text in three staging chunks (70 M characters, ragged
+    end), ~0.1 % other characters patched in; the buffer read back equals the plainly packed symbols byte for byte,
+    and a run on it gives the oracle's records."""
+    from havac_amd.hw_client import HavacHwClient
+    rng = np.random.default_rng(17)
+    n = 70_000_003
+    sym = rng.integers(0, 4, size=n, dtype=np.uint8)
+    letters = np.frombuffer(b"ACGTacgt", np.uint8)
+    chars = letters[sym + 4 * rng.integers(0, 2, size=n, dtype=np.uint8)]
+    cols = np.unique(rng.integers(0, n, size=70_000)).astype(np.uint64)
+    chars[cols.astype(np.int64)] = np.frombuffer(b"N\0RYKMSWn*", np.uint8)[rng.integers(0, 10, size=cols.size)]
+    syms = rng.integers(0, 4, size=cols.size, dtype=np.uint8)
+    sym[cols.astype(np.int64)] = syms
+    ncolumns = -(-n // synth.SEGMENT) * synth.SEGMENT
+    want = np.zeros(ncolumns, np.uint8)
+    want[:n] = sym
+    c = HavacHwClient()
+    c.writeSequenceChars(chars, cols, syms)
+    got = c.readSequence(ncolumns // 4)
+    assert np.array_equal(got, synth.pack_2bit(want))
+    model, cons = synth.dfam_like_model(64, 5)
+    c.writePhmm(model)
+    c.setHitCapacity(1 << 20)
+    c.invokeHavacSsvAsync()
+    assert c.waitForHavacSsvAsync() == 4
+    assert np.array_equal(c.getHitList(), oracle.ssv_fast(want, model))
+    # a short text: one ragged chunk, no patches, then patch-argument errors
+    c.writeSequenceChars(b"ACGTACGTAC")
+    assert np.array_equal(c.readSequence(3072)[:3], synth.pack_2bit(np.array([0, 1, 2, 3, 0, 1, 2, 3, 0, 1, 0, 0], np.uint8)))
+    assert not c.readSequence(3072)[3:].any()
+    with pytest.raises(Exception):
+        c.writeSequenceChars(b"ACGT", [3, 2], [0, 0])          # not ascending
+    with pytest.raises(Exception):
+        c.writeSequenceChars(b"ACGT", [20000], [1])            # outside the padded sequence
+    c.close()
+
+
+def test_havac_packs_on_the_gpu_by_default(tmp_path, oracle):
+    """Havac::loadSequence with packing on the GPU (the default) and on the host: same raw records for the same
+    rand() seed, with ambiguity codes in the file."""
+    import ctypes as C
+    from havac_amd import havac
+    fa, hmm = write_inputs(tmp_path, [90, 200], [30000, 9000, 40], seed=13)
+    runs = []
+    for on_gpu in (True, False):
+        h = havac.Havac(0, 0.02)
+        h.setDevicePacking(on_gpu)
+        h.loadPhmm(hmm)
+        C.CDLL(None).srand(77)
+        h.loadSequence(fa)
+        h.runHardwareClient()
+        h.getHitsFromFinishedRun()
+        runs.append(h.rawHits())
+        h.close()
+    assert runs[0].size > 0 and np.array_equal(runs[0], runs[1])
+    table, lens = havac.project_hmm(hmm, 0.02)
+    packed, nchars, nrec = havac.pack_fasta(fa, seed=77)
+    assert np.array_equal(runs[0], oracle.ssv_mt(oracle.unpack_2bit(packed), table))

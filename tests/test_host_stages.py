@@ -267,3 +267,32 @@ def test_hits_merge_into_windows():
     assert havac.merge_windows([], model_lengths, record_lengths) == []
     # hits naming a model or record that does not exist are dropped, not an error
     assert havac.merge_windows([havac.HavacHit(1, 9, 0, 0), havac.HavacHit(1, 0, 0, 9)], model_lengths, record_lengths) == []
+
+
+def test_text_and_patches_reproduce_the_host_packer(tmp_path):
+    """what loadSequence hands to the GPU packer -- the text plus (column, symbol) for every
+    character that is not a/c/g/t -- gives the host packer's bytes when a/c/g/t are packed plainly and the patches
+    applied, for the same rand() seed.  (A record's terminator always follows its last residue, so the bit a 'Y'
+    spills into the next field is always cleared by that next character, as in the host packer.)"""
+    rng = np.random.default_rng(3)
+    alphabet = list("ACGTacgtNRYKMSWBDHVnry")
+    records = [(f"s{k}", "".join(rng.choice(alphabet, size=int(rng.integers(1, 5000)), p=[.2] * 4 + [.02] * 4 + [.12 / 14] * 14)))
+               for k in range(7)]
+    records.append(("last", "ACGTY"))                      # 'Y' as the last residue of the file
+    fa = tmp_path / "amb.fa"
+    synth.write_fasta(str(fa), records)
+    code = np.zeros(256, np.uint8)
+    for ch, v in zip("ACGT", range(4)):
+        code[ord(ch)] = code[ord(ch.lower())] = v
+    for seed in range(8):
+        packed, nchars, nrec = havac.pack_fasta(str(fa), seed=seed)
+        chars, cols, syms = havac.text_and_patches(str(fa), seed=seed)
+        assert chars.size == nchars and (np.diff(cols.astype(np.int64)) > 0).all() and syms.max() <= 3
+        sym = np.zeros(packed.size * 4, np.uint8)
+        sym[:chars.size] = code[chars]
+        sym[cols.astype(np.int64)] = syms
+        assert np.array_equal(synth.pack_2bit(sym), packed), seed
+        plain = code[chars] != 0
+        plain |= np.isin(chars, np.frombuffer(b"Aa", np.uint8))
+        assert np.array_equal(np.flatnonzero(~plain), cols[cols < nchars].astype(np.int64))   # exactly the other characters
+        assert cols[-1] == nchars - 1                         # the last patch is the last record's terminator
