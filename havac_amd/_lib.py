@@ -37,6 +37,8 @@ SIGNATURES = {
     "havac_dev_abort": (C.c_int, [_vp]),
     "havac_dev_num_hits": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "havac_dev_read_hits": (C.c_int, [_vp, C.c_void_p, C.c_uint32]),
+    "havac_dev_num_hits64": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "havac_dev_read_hits64": (C.c_int, [_vp, C.c_void_p, C.c_uint64]),
     "havac_dev_last_run_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "havac_dev_last_error": (C.c_char_p, [_vp]),
     "havac_ssv_ctx_create": (C.c_int, [C.POINTER(C.c_void_p)]),

@@ -707,26 +707,39 @@ extern "C" int havac_dev_abort(havac_dev* d) {
     return sync_all(d);
 }
 
-extern "C" int havac_dev_num_hits(havac_dev* d, uint32_t* count) {
+extern "C" int havac_dev_num_hits64(havac_dev* d, uint64_t* count) {
     if (!d || !count) return HAVAC_E_ARGUMENT;
     if (!d->has_run) { d->err = "num hits was not set by the client!"; return HAVAC_E_RUNTIME; }   // HavacHwClient.cpp:181-183
     if (!d->finished) { int s = havac_dev_wait(d, 0); if (s < 0) return s; }
     if (d->failed) return d->overflowed ? HAVAC_E_HIT_OVERFLOW : HAVAC_E_RUNTIME;
-    *count = (uint32_t)d->found;
+    *count = d->found;
     return HAVAC_OK;
 }
 
-extern "C" int havac_dev_read_hits(havac_dev* d, uint64_t* out, uint32_t n) {
+extern "C" int havac_dev_num_hits(havac_dev* d, uint32_t* count) {
+    if (!count) return HAVAC_E_ARGUMENT;
+    uint64_t found = 0;
+    int rc = havac_dev_num_hits64(d, &found);
+    if (rc) return rc;
+    if (found > 0xffffffffull) {          // the reference's counter is 32 bits wide (host/HavacHwClient.cpp:172-186)
+        d->err = std::to_string(found) + " hits do not fit the 32-bit count of this entry point: use havac_dev_num_hits64";
+        return HAVAC_E_HIT_OVERFLOW;
+    }
+    *count = (uint32_t)found;
+    return HAVAC_OK;
+}
+
+extern "C" int havac_dev_read_hits64(havac_dev* d, uint64_t* out, uint64_t n) {
     if (!d || (!out && n)) return HAVAC_E_ARGUMENT;
-    uint32_t have = 0;
-    int rc = havac_dev_num_hits(d, &have);
+    uint64_t have = 0;
+    int rc = havac_dev_num_hits64(d, &have);
     if (rc) return rc;
     if (n > have) n = have;
     // shard order is device order: the GPUs' lists are simply laid end to end
     uint64_t at = 0;
     for (DevicePart& p : d->parts) {
         if (at >= n) break;
-        uint64_t take = p.found < (uint64_t)n - at ? p.found : (uint64_t)n - at;
+        uint64_t take = p.found < n - at ? p.found : n - at;
         if (take == 0) continue;
         HIP_TRY(d->err, hipSetDevice(p.device));
         HIP_TRY(d->err, hipMemcpy(out + at, p.d_hits, (size_t)take * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -734,6 +747,8 @@ extern "C" int havac_dev_read_hits(havac_dev* d, uint64_t* out, uint32_t n) {
     }
     return HAVAC_OK;
 }
+
+extern "C" int havac_dev_read_hits(havac_dev* d, uint64_t* out, uint32_t n) { return havac_dev_read_hits64(d, out, n); }
 
 extern "C" int havac_dev_last_run_ms(havac_dev* d, float* ssv_kernel_ms, float* total_ms) {
     if (!d) return HAVAC_E_ARGUMENT;

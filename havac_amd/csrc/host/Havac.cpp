@@ -203,10 +203,10 @@ vector<HavacHit> havacResolveHits(const vector<uint64_t> &rawHits, const FastaVe
 }
 
 vector<HavacHit> Havac::getHitsFromFinishedRun() {
-    uint32_t n = 0;
-    check(havac_dev_num_hits(dev_, &n));
+    uint64_t n = 0;                                        // 64-bit: several GPUs can hold more than 2^32 - 1 records
+    check(havac_dev_num_hits64(dev_, &n));
     rawHits_.assign(n, 0);
-    if (n) check(havac_dev_read_hits(dev_, rawHits_.data(), n));
+    if (n) check(havac_dev_read_hits64(dev_, rawHits_.data(), n));
     // both strands: a record of the second half is the record at (column - forwardColumns_) of the first
     vector<uint64_t> forward = rawHits_;
     vector<bool> reverse(rawHits_.size(), false);

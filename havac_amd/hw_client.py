@@ -127,15 +127,15 @@ class HavacHwClient:
         return self._check(self._L.havac_dev_abort(self._h))
 
     def getNumHits(self) -> int:
-        n = C.c_uint32(0)
-        self._check(self._L.havac_dev_num_hits(self._h, C.byref(n)))
+        n = C.c_uint64(0)          # the 64-bit entry point: several GPUs behind one handle can exceed 2^32 - 1 records
+        self._check(self._L.havac_dev_num_hits64(self._h, C.byref(n)))
         return n.value
 
     def getHitList(self) -> np.ndarray:
         n = self.getNumHits()
         out = np.empty(n, dtype=np.uint64)
         if n:
-            self._check(self._L.havac_dev_read_hits(self._h, out.ctypes.data, n))
+            self._check(self._L.havac_dev_read_hits64(self._h, out.ctypes.data, n))
         return out
 
     def lastRunMs(self):

@@ -152,6 +152,10 @@ int havac_dev_abort(havac_dev *dev);
  * Valid after a completed run.  read_hits copies min(n, count) records in
  * device order. */
 int havac_dev_num_hits(havac_dev *dev, uint32_t *count);
+/* The same with 64-bit counts: several GPUs behind one handle can hold more than 2^32 - 1 records (C4: 4.5e9);
+ * havac_dev_num_hits returns HAVAC_E_HIT_OVERFLOW then instead of a truncated count. */
+int havac_dev_num_hits64(havac_dev *dev, uint64_t *count);
+int havac_dev_read_hits64(havac_dev *dev, uint64_t *out, uint64_t n);
 int havac_dev_read_hits(havac_dev *dev, uint64_t *out, uint32_t n);
 
 /* Device time of the last completed run in milliseconds (HIP events on the

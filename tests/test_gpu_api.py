@@ -373,3 +373,35 @@ def test_havac_packs_on_the_gpu_by_default(tmp_path, oracle):
     table, lens = havac.project_hmm(hmm, 0.02)
     packed, nchars, nrec = havac.pack_fasta(fa, seed=77)
     assert np.array_equal(runs[0], oracle.ssv_mt(oracle.unpack_2bit(packed), table))
+
+
+def test_more_than_2_to_32_records_behind_one_handle():
+    """Four device parts behind one handle report 4.4e9 records between them (C4 on eight GPUs reaches 4.5e9): the
+    reference-shaped 32-bit count says so instead of wrapping, the 64-bit entry points give the count and the records.
+    Every score is +127, so each diagonal crosses 256 on every third row: the expected list is known in closed form."""
+    import ctypes as C
+    from havac_amd import _lib
+    from havac_amd.hw_client import HavacHwClient
+    nseg, nrows = 100, 10_752
+    n = nseg * synth.SEGMENT
+    c = HavacHwClient(deviceIndices=[0, 0, 0, 0])
+    per_part = n // 4 * (nrows // 3)                             # a third of the shard's cells, give or take the left edge
+    c.setHitCapacity(per_part + (1 << 25))
+    c.writeSequence(np.zeros(n // 4, np.uint8))
+    c.writePhmm(np.full((nrows, 4), 127, np.int8))
+    c.invokeHavacSsvAsync()
+    assert c.waitForHavacSsvAsync() == 4
+    # cell (p, s) is the (min(p, s) + 1)-th of its diagonal and hits iff that is a multiple of 3
+    s_ = np.arange(nrows, dtype=np.int64)
+    want = int(((s_ + 1) // 3 + np.where((s_ + 1) % 3 == 0, nrows - s_ - 1, 0)).sum()) + (n - nrows) * (nrows // 3)
+    assert want > (1 << 32)
+    L = _lib.load()
+    n32 = C.c_uint32(0)
+    assert L.havac_dev_num_hits(c._h, C.byref(n32)) == _lib.E_HIT_OVERFLOW
+    assert c.getNumHits() == want
+    first = np.empty(6, np.uint64)
+    assert L.havac_dev_read_hits64(c._h, first.ctypes.data, 6) == 0
+    # device order: segment 0, then rows ascending; row 2 is the first with hits, on columns 2, 3, ... of the segment
+    rows, cols = first >> np.uint64(40), first & np.uint64(0x3FFF)
+    assert rows.tolist() == [2] * 6 and cols.tolist() == [2, 3, 4, 5, 6, 7]
+    c.close()
