@@ -35,6 +35,7 @@ int guarded(havac_host *h, F &&f) {
 
 int copyHits(const vector<HavacHit> &hits, uint64_t *sp, uint32_t *si, uint32_t *pp, uint32_t *pi, uint32_t cap,
              uint32_t *count) {
+    if (hits.size() > 0xffffffffull) return HAVAC_E_HIT_OVERFLOW;   // these FFI wrappers count in 32 bits; the C++ class does not
     if (count) *count = (uint32_t)hits.size();
     for (uint32_t i = 0; i < cap && i < hits.size(); i++) {
         if (sp) sp[i] = hits[i].sequencePosition;
