@@ -281,7 +281,7 @@ static void *fast_main(void *arg) {
     for (uint64_t b = (uint64_t)j->thread; b < j->nbands && !j->failed; b += (uint64_t)j->nthreads)
         fast_band(j, first + (int64_t)(b * FAST_BAND), score);
     free(score);
-    if (!j->failed) qsort(j->keys, (size_t)j->count, sizeof(uint64_t), cmp_u64);
+    if (!j->failed && j->count) qsort(j->keys, (size_t)j->count, sizeof(uint64_t), cmp_u64);
     return NULL;
 }
 
