@@ -43,13 +43,14 @@
 //    indexed statically in the fully unrolled chunk, so the slide is free.
 //  * HITS are rare (about 1e-5 per cell on Dfam-like models): after each step
 //    pair the 16 score registers are OR-ed and one wave-wide test looks at the
-//    low bytes; only then the slow path sorts out which step crossed, puts the
-//    crossed cells back to score 0 (0x7fff + 1 = 0x8000; test/softSsv/
-//    SoftSsv.cpp:43-44) -- taking the second step again for cells that crossed
-//    on the first -- and parks one mask per step in LDS.  Twice per chunk a
-//    scalar-unit routine turns masks into records in an LDS stage; records
-//    leave with one returning atomic per burst of 128 and one per block at the
-//    end of the tile, and are put in the FPGA's order afterwards.
+//    low bytes; only then the slow path runs, one marked lane at a time and on
+//    the SCALAR unit (v_readlane of the lane's registers, everything else SALU):
+//    it sorts out which step crossed, puts the crossed cells back to score 0
+//    (0x7fff + 1 = 0x8000; test/softSsv/SoftSsv.cpp:43-44) -- taking the second
+//    step again for cells that crossed on the first -- and writes the records
+//    into an LDS stage.  Records leave with one returning atomic per burst of
+//    128 and one per block at the end of the tile, and are put in the FPGA's
+//    order afterwards.
 //
 // Roofline: integer VALU issue; HBM
 // traffic is N/4 + 4*rows + 8*hits bytes per launch, thousands of cells per byte.
@@ -72,12 +73,11 @@ constexpr uint32_t kCrossedBits = 0x00010001u;    // bit 0 of either cell: set o
 constexpr uint32_t kOutsideWord = 0x80008000u;    // match word "score -128" for both cells
 constexpr uint32_t kPadRow = 0x80808080u;         // a row outside the model: -128 for every symbol
 
-// per-wave LDS: 16 step-pair tables of 17 entries x 8 B, the parked hit masks of half a chunk, the record stage
+// per-wave LDS: 16 step-pair tables of 17 entries x 8 B, the record stage
 constexpr int kPairStride = 17 * 8;               // 16 symbol-pair codes + the "outside the matrix" entry
 constexpr uint32_t kOutsideCode = 16 * 8;         // byte offset of that entry
 constexpr int kTableBytes = 2304;                 // 16 x 136 = 2176, rounded up to a multiple of 128
 constexpr int kHitStage = 128;                    // records staged per wave (1 KiB)
-constexpr int kMaskSteps = kChunkRows / 2;        // masks are drained twice per chunk
 
 // sort key of a hit: (segment, row, column-in-segment) -- the FPGA's emission
 // order (device/HavacHls.cpp:151-152,264; device/HitReporting.cpp:178-337)
@@ -181,14 +181,13 @@ __device__ __forceinline__ uint2 load_symbols(const uint8_t* __restrict__ seq, i
 // ---- per-wave LDS ------------------------------------------------------------
 struct __attribute__((aligned(128))) WaveLds {
     uint8_t table[kTableBytes];            // match words of the current chunk
-    uint32_t masks[kMaskSteps * 64];       // parked hit masks, [step in half chunk][lane]
     uint64_t stage[kHitStage];             // records waiting for the next burst
 };
 
 // ---- hit queue --------------------------------------------------------------
 // Counterpart of the FPGA's five-stage hit sieve (device/HitReporting.cpp:12-417).
-// A wave that sees a crossing parks one 32-bit mask per lane and step in LDS.
-// Twice per chunk the parked masks are turned into records, staged in LDS and
+// A wave that sees a crossing turns it into a record at once (step_pair's slow
+// path, on the scalar unit) and stages it in LDS; staged records are
 // appended to the global queue in bursts: one returning atomic per burst
 // instead of one per hit (a single counter word sustains only ~90 returning
 // atomics per microsecond chip-wide, which capped the first version of this
@@ -224,62 +223,39 @@ __device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t sta
     return 0;
 }
 
-// Twice per chunk, only if some step of the half chunk parked masks.
-// `steps_with_hits` has bit r set for step step0 + r.  Bit q of a lane's mask
-// stands for register 2*(q & 7) + (q >> 4), cell (q >> 3) & 1 (see crossed_mask).
-// At step t the low cell of register g of lane l is (row t, column c) and the
-// high cell (row t - 1, column c), with c = wave_diag0 + 32*l + 2*g + t.
-__device__ __noinline__ uint32_t drain_steps(const HitSink sink, uint32_t staged_in, uint32_t steps_in,
-                                             uint32_t step0_in, int64_t wave_diag0_in, int lane) {
-    // Arguments arrive in VGPRs; everything but `lane` is wave-uniform.  Back into SGPRs: the loops below then run
-    // on the scalar unit, which this VALU-bound kernel leaves idle; per hit the VALU only moves the record to LDS.
-    uint32_t staged = __builtin_amdgcn_readfirstlane(staged_in);
-    uint32_t steps_with_hits = __builtin_amdgcn_readfirstlane(steps_in);
-    const uint32_t step0 = __builtin_amdgcn_readfirstlane(step0_in);
-    const int64_t wave_diag0 = uniform_i64(wave_diag0_in);
-    const int64_t col_begin = uniform_i64(sink.col_begin), col_end = uniform_i64(sink.col_end);
-    const uint32_t row_bits = __builtin_amdgcn_readfirstlane(sink.row_bits);
-    const auto lds = (__attribute__((address_space(3))) WaveLds*)sink.lds;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    while (steps_with_hits) {
-        const uint32_t r = (uint32_t)__builtin_ctz(steps_with_hits);
-        steps_with_hits &= steps_with_hits - 1;
-        const uint32_t t = step0 + r;
-        const uint32_t mask = lds->masks[r * 64 + lane];
-        unsigned long long lanes = __ballot(mask != 0);
-        while (lanes) {
-            const uint32_t src = (uint32_t)__builtin_ctzll(lanes);
-            lanes &= lanes - 1;
-            uint32_t m = __builtin_amdgcn_readlane(mask, src);
-            while (m) {
-                const uint32_t q = (uint32_t)__builtin_ctz(m);      // bit q: register 2*(q & 7) + (q >> 4), cell (q >> 3) & 1
-                m &= m - 1;
-                const uint32_t reg = 2 * (q & 7) + (q >> 4);
-                const uint32_t high = (q >> 3) & 1;
-                const int64_t column = wave_diag0 + (int64_t)(32 * src + 2 * reg + t);
-                if (column < col_begin || column >= col_end) continue;   // halo columns belong to the neighbouring shard
-                const uint64_t key = hit_key(t - high, (uint64_t)column, row_bits);
-                if (lane == 0) lds->stage[staged] = key;
-                staged++;
-                if (staged == kHitStage) staged = flush_hits(sink, staged, lane);
-            }
-        }
-    }
-    return staged;
+// A full stage leaves with one returning atomic (a real call: rare, and its registers stay out of the hot loop).
+__device__ __noinline__ uint32_t flush_full(const HitSink sink, uint32_t staged, int lane) {
+    return flush_hits(sink, __builtin_amdgcn_readfirstlane(staged), lane);
 }
 
-// One bit per cell of the lane: set where the cell's low byte is non-zero (it crossed 256).
-// Bit q = 8*b + j stands for register 2j + (b >> 1), cell b & 1: the layout that costs least
-// here, two registers per v_perm; drain_steps undoes it.
-__device__ __forceinline__ uint32_t crossed_mask(const uint32_t (&v)[kRegs]) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int j = 0; j < kRegs / 2; j++) {
-        // bytes: [v[2j] low cell, v[2j] high cell, v[2j+1] low cell, v[2j+1] high cell], bit 0 = crossed
-        const uint32_t w = __builtin_amdgcn_perm(v[2 * j + 1], v[2 * j], 0x06040200u) & 0x01010101u;
-        m |= w << j;
+// Two int16 saturating adds on the scalar unit (the slow path's copy of v_pk_add_i16 ... clamp).
+__device__ __forceinline__ uint32_t scalar_sat_add_pk16(uint32_t a, uint32_t b) {
+    int lo = (int)(short)(a & 0xffffu) + (int)(short)(b & 0xffffu);
+    int hi = (int)(short)(a >> 16) + (int)(short)(b >> 16);
+    lo = lo < -32768 ? -32768 : (lo > 32767 ? 32767 : lo);
+    hi = hi < -32768 ? -32768 : (hi > 32767 ? 32767 : hi);
+    return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+}
+
+// Records of one lane's crossings at step t.  Bit i of `marks` = the low cell of register i, bit 16 + i = its high
+// cell.  At step t the low cell of register i of lane l is (row t, column c) and the high cell (row t - 1, column c),
+// with c = wave_diag0 + 32*l + 2*i + t.  Everything here is wave-uniform: it runs on the scalar unit, which this
+// VALU-bound kernel leaves idle; per record the VALU only moves the key to the LDS stage.
+__device__ __forceinline__ uint32_t emit_marks(const HitSink& sink, uint32_t staged, uint32_t marks, uint32_t t,
+                                               uint32_t l, int64_t wave_diag0, int lane) {
+    const auto lds = (__attribute__((address_space(3))) WaveLds*)sink.lds;
+    while (marks) {
+        const uint32_t q = (uint32_t)__builtin_ctz(marks);
+        marks &= marks - 1;
+        const uint32_t reg = q & 15, high = q >> 4;
+        const int64_t column = wave_diag0 + (int64_t)(32 * l + 2 * reg + t);
+        if (column < sink.col_begin || column >= sink.col_end) continue;   // halo columns belong to the neighbouring shard
+        const uint64_t key = hit_key(t - high, (uint64_t)column, sink.row_bits);
+        if (lane == 0) lds->stage[staged] = key;
+        staged++;
+        if (staged == kHitStage) staged = flush_full(sink, staged, lane);
     }
-    return m;
+    return staged;
 }
 
 // both steps' match words of one register: one ds_read_b64, table of step pair P, entry `code_addr`
@@ -299,11 +275,13 @@ __device__ __forceinline__ u32x2 match_words(uint32_t code_addr) {
 // plain 2.62 ms, both asm 2.49 ms, first asm + second plain 2.39 ms).
 template <int P>
 __device__ __forceinline__ void step_pair(uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
-                                          uint32_t* __restrict__ masks, uint32_t& steps_with_hits, int lane) {
+                                          const HitSink& sink, uint32_t& staged, uint32_t step0, int64_t wave_diag0,
+                                          int lane) {
     uint32_t any = 0;
     u32x2 m[kRegs];
 #pragma unroll
     for (int i = 0; i < kRegs; i++) m[i] = match_words<P>(C[P + i]);
+    __builtin_amdgcn_sched_barrier(0);      // all 16 reads in flight before the first add waits (hipcc otherwise staggers them)
 #pragma unroll
     for (int i = 0; i < kRegs; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(cur[i]) : "v"(m[i].x));
 #pragma unroll
@@ -312,39 +290,47 @@ __device__ __forceinline__ void step_pair(uint32_t (&cur)[kRegs], uint32_t (&nxt
         any |= nxt[i];
     }
     if (__builtin_expect(__any((any & kCrossedBits) != 0), 0)) {
-        uint32_t any_first = 0;
-#pragma unroll
-        for (int i = 0; i < kRegs; i++) any_first |= cur[i];
-        uint32_t mask0 = 0;
-        if (__any((any_first & kCrossedBits) != 0)) {
-            // crossed 256 on the first step: such a cell holds exactly 0x7fff and restarts from 0
-            // (SoftSsv.cpp:43-44); + 1 makes it 0x8000 = score 0, then its second step is taken again
-            mask0 = crossed_mask(cur);
+        // (the lane mask is taken again inside: the hot test stays v_cmp -> vcc -> s_cbranch_vccnz)
+        unsigned long long lanes = __ballot((any & kCrossedBits) != 0);
+        // Slow path, one lane at a time on the scalar unit (typically one lane, one register).  A crossed cell holds
+        // exactly 0x7fff; "restart from 0" (SoftSsv.cpp:43-44) is + 1 on that int16 (0x8000 = score 0).  A cell that
+        // crossed on the first step still shows its mark on `nxt`; it gets the + 1 on `cur` and takes the second step again.
+        do {
+            const uint32_t l = (uint32_t)__builtin_ctzll(lanes);
+            lanes &= lanes - 1;
+            const bool mine = (uint32_t)lane == l;
+            uint32_t first = 0, second = 0;     // bit i: low cell of register i, bit 16 + i: its high cell
 #pragma unroll
             for (int i = 0; i < kRegs; i++) {
-                cur[i] += cur[i] & kCrossedBits;
-                nxt[i] = sat_add_pk16(cur[i], match_words<P>(C[P + i]).y);
+                uint32_t n = __builtin_amdgcn_readlane(nxt[i], l);
+                if (n & kCrossedBits) {
+                    uint32_t c = __builtin_amdgcn_readlane(cur[i], l);
+                    const uint32_t f = c & kCrossedBits;
+                    if (f) {
+                        c += f;
+                        n = scalar_sat_add_pk16(c, __builtin_amdgcn_readlane(match_words<P>(C[P + i]).y, l));
+                        first |= f << i;
+                    }
+                    const uint32_t sec = n & kCrossedBits;
+                    n += sec;
+                    second |= sec << i;
+                    nxt[i] = mine ? n : nxt[i];
+                }
             }
-        }
-        // second-step crossings: the same + 1
-        const uint32_t mask1 = crossed_mask(nxt);
-#pragma unroll
-        for (int i = 0; i < kRegs; i++) nxt[i] += nxt[i] & kCrossedBits;
-        constexpr int r = (2 * P) % kMaskSteps;
-        masks[r * 64 + lane] = mask0;
-        masks[(r + 1) * 64 + lane] = mask1;
-        steps_with_hits |= 3u << r;
+            staged = emit_marks(sink, staged, first, step0 + 2 * P, l, wave_diag0, lane);
+            staged = emit_marks(sink, staged, second, step0 + 2 * P + 1, l, wave_diag0, lane);
+        } while (lanes);
     }
 }
 
 // pairs First .. First+N-1; the scores are in `a` on entry and, N being even, in `a` again on exit
 template <int First, int... I>
 __device__ __forceinline__ void step_pairs(uint32_t (&a)[kRegs], uint32_t (&b)[kRegs], const uint32_t (&C)[32],
-                                           uint32_t* __restrict__ masks, uint32_t& steps_with_hits, int lane,
-                                           std::integer_sequence<int, I...>) {
+                                           const HitSink& sink, uint32_t& staged, uint32_t step0, int64_t wave_diag0,
+                                           int lane, std::integer_sequence<int, I...>) {
     static_assert(sizeof...(I) % 2 == 0, "an even number of pairs returns the scores to the first set");
-    ((I % 2 == 0 ? step_pair<First + I>(a, b, C, masks, steps_with_hits, lane)
-                 : step_pair<First + I>(b, a, C, masks, steps_with_hits, lane)), ...);
+    ((I % 2 == 0 ? step_pair<First + I>(a, b, C, sink, staged, step0, wave_diag0, lane)
+                 : step_pair<First + I>(b, a, C, sink, staged, step0, wave_diag0, lane)), ...);
 }
 
 // selector of the match word of symbol a: bytes [0x0c, a, 0x0c, 4 + a]; with v_perm(S0 = row t-1, S1 = row t) it
@@ -461,21 +447,14 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
             next_rows = fetch_rows(p0 + kChunkRows);              // rows[] has kModelSlack words behind the model
             next_symbols = fetch_symbols(p0 + kChunkRows + 32);
 
-            uint32_t steps_with_hits = 0;   // wave-uniform
-            step_pairs<0>(x, x2, C, lds->masks, steps_with_hits, lane, std::make_integer_sequence<int, kChunkPairs / 2>{});
-            if (steps_with_hits) staged = drain_steps(sink, staged, steps_with_hits, (uint32_t)p0, d0, lane);
-            steps_with_hits = 0;
-            step_pairs<kChunkPairs / 2>(x, x2, C, lds->masks, steps_with_hits, lane, std::make_integer_sequence<int, kChunkPairs / 2>{});
-            if (steps_with_hits) staged = drain_steps(sink, staged, steps_with_hits, (uint32_t)p0 + kMaskSteps, d0, lane);
+            step_pairs<0>(x, x2, C, sink, staged, (uint32_t)p0, d0, lane, std::make_integer_sequence<int, kChunkPairs>{});
         }
         if (p_hi == (int64_t)nrows_padded) {
             // the high cells run one row behind: one more step gives them the model's last row
             build_tables(next_rows);                               // fetched for p_hi by the last chunk
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-            uint32_t steps_with_hits = 0;
-            step_pair<0>(x, x2, C, lds->masks, steps_with_hits, lane);
-            if (steps_with_hits) staged = drain_steps(sink, staged, steps_with_hits, (uint32_t)p_hi, d0, lane);
+            step_pair<0>(x, x2, C, sink, staged, (uint32_t)p_hi, d0, lane);
         }
     }   // this wave's tile
 
