@@ -337,7 +337,11 @@ __device__ __forceinline__ void step_pairs(uint32_t (&a)[kRegs], uint32_t (&b)[k
 // yields (row_t[a] << 8) | (row_tm1[a] << 24)
 __device__ __forceinline__ uint32_t word_selector(uint32_t a) { return 0x040c000cu + a * 0x01000100u; }
 
-__global__ __launch_bounds__(64 * kWavesPerBlock, 4)   // 4 waves per SIMD (<= 128 VGPRs): 3 is 6 % slower, 5 spills badly
+// 5 waves per SIMD: 96 VGPRs; hipcc keeps the six registers of the chunk-ahead prefetch (next model rows, next symbols)
+// in scratch across the 16 step pairs, which costs nothing measurable.  Measured on C2 with the scalar slow path:
+// 4 waves (106 VGPRs) 2.21 ms, 5 waves 2.15 ms; without hits 2.02 / 2.005 ms.  (With the earlier vector slow path the
+// kernel needed 121 VGPRs and 5 waves spilled badly; 3 waves are 7 % slower.)
+__global__ __launch_bounds__(64 * kWavesPerBlock, 5)
 void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, const uint32_t* __restrict__ rows,
                      const uint32_t nrows_padded, const int64_t first_diag, const uint32_t tile_begin,
                      const uint32_t tile_end, const int64_t col_begin, const int64_t col_end,
