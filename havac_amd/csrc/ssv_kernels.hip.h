@@ -337,10 +337,9 @@ __device__ __forceinline__ void step_pairs(uint32_t (&a)[kRegs], uint32_t (&b)[k
 // yields (row_t[a] << 8) | (row_tm1[a] << 24)
 __device__ __forceinline__ uint32_t word_selector(uint32_t a) { return 0x040c000cu + a * 0x01000100u; }
 
-// 5 waves per SIMD: 96 VGPRs; hipcc keeps the six registers of the chunk-ahead prefetch (next model rows, next symbols)
-// in scratch across the 16 step pairs, which costs nothing measurable.  Measured on C2 with the scalar slow path:
-// 4 waves (106 VGPRs) 2.21 ms, 5 waves 2.15 ms; without hits 2.02 / 2.005 ms.  (With the earlier vector slow path the
-// kernel needed 121 VGPRs and 5 waves spilled badly; 3 waves are 7 % slower.)
+// 5 waves per SIMD: 96 VGPRs, no scratch.  Measured on C2 with the scalar slow path: 4 waves (106 VGPRs) 2.21 ms,
+// 5 waves 2.12 ms; without hits 2.02 / 1.98 ms.  (With the earlier vector slow path the kernel needed 121 VGPRs and
+// 5 waves spilled badly; 3 waves are 7 % slower.)
 __global__ __launch_bounds__(64 * kWavesPerBlock, 5)
 void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, const uint32_t* __restrict__ rows,
                      const uint32_t nrows_padded, const int64_t first_diag, const uint32_t tile_begin,
@@ -434,7 +433,10 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
             for (int a = 0; a < 4; a++) out[a] = u32x2{__builtin_amdgcn_perm(r.r0, r.r1, word_selector(a)), second};
         };
         expand(fetch_symbols(p_lo), p_lo);
-        // the global loads of a chunk are issued one chunk ahead, so their latency hides behind 16 step pairs
+        // The global loads of a chunk (12 B of model rows and 8 B of symbols per lane) are issued at the END of the chunk
+        // before it and consumed at its top: no register carries them across the 16 step pairs (held there they cost six
+        // VGPRs, i.e. scratch at 96), and the latency that is exposed this way is covered by the other four waves of
+        // the SIMD (measured: 2.12 ms against 2.16 ms with the loads issued a whole chunk ahead).
         ModelRows next_rows = fetch_rows(p_lo);
         uint3 next_symbols = fetch_symbols(p_lo + 32);
 
@@ -448,10 +450,11 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
             expand(next_symbols, p0 + 32);
-            next_rows = fetch_rows(p0 + kChunkRows);              // rows[] has kModelSlack words behind the model
-            next_symbols = fetch_symbols(p0 + kChunkRows + 32);
 
             step_pairs<0>(x, x2, C, sink, staged, (uint32_t)p0, d0, lane, std::make_integer_sequence<int, kChunkPairs>{});
+            asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the step pairs
+            next_rows = fetch_rows(p0 + kChunkRows);              // rows[] has kModelSlack words behind the model
+            next_symbols = fetch_symbols(p0 + kChunkRows + 32);
         }
         if (p_hi == (int64_t)nrows_padded) {
             // the high cells run one row behind: one more step gives them the model's last row
