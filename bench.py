@@ -66,9 +66,9 @@ LDS_BYTES_PER_CELL = 2
 LDS_PEAK_TBS = 157.3
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per launch of ssv_diag_kernel on the default workload, from the separate rocprofv3 --pmc
-# passes in profiles/r01e_pmc_c2.csv: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 with the gfx950 FETCH_SIZE
+# passes in profiles/r01f_pmc_c2.csv: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 with the gfx950 FETCH_SIZE
 # correction of MI355X_MICROARCH.md (uncalibrated for 8-byte-per-lane loads: an upper bound).
-PMC_TRAFFIC_C2_BYTES = (2 * 15039.5 + 8467.1) * 1024
+PMC_TRAFFIC_C2_BYTES = (2 * 15039.3 + 8457.0) * 1024
 
 
 def plant_packed(packed: np.ndarray, consensus: np.ndarray, nreal: int, every=1_000_000, length=300, sub=0.15,
