@@ -405,3 +405,33 @@ def test_more_than_2_to_32_records_behind_one_handle():
     rows, cols = first >> np.uint64(40), first & np.uint64(0x3FFF)
     assert rows.tolist() == [2] * 6 and cols.tolist() == [2, 3, 4, 5, 6, 7]
     c.close()
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the fields the driver reads, the roofline and cpu_baseline objects included
+    (small workload here; the default is config C2)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--rows", "256",
+                        "--columns-per-gpu", str(400 * synth.SEGMENT), "--cpu-cols-per-core", "20000"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "GCUPS" and d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["cells_per_step"] / d["ms_per_step"] / 1e6) < 0.01 * d["value"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"], key
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in d["cpu_baseline"], key
+    assert d["cpu_baseline"]["hits_match_gpu"] is True
+    assert d["cpu_baseline"]["vectorised_port"]["whole_hit_list_matches_gpu"] is True
