@@ -1,41 +1,55 @@
 #!/usr/bin/env python3
 """bench.py -- GCUPS of the SSV hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5]
+
+With --gpus N > 1 and no launcher around it (WORLD_SIZE unset) this script starts its own N workers
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...`, as a child process, before
+anything in this process has touched a GPU) and exits with their code; under a launcher it is one rank.
 
 A step is one whole pass of the hot path over one batch of synthetic input that
 is already resident in HBM: model padding copy + SSV kernel + hit compaction +
 ordering of the hit records into the reference's device order (+ for N > 1 the
 RCCL gather of the records to rank 0, where the rank lists concatenate to the
-ordered whole).  By default three passes are in flight (--pipeline-depth), each with its own
+ordered whole).  For passes of up to 1e12 cells three passes are in flight (--pipeline-depth), each with its own
 context, hit buffer and HIP stream: while the host waits for the hit count of pass k, orders
 its records and gathers them, the SSV kernel of pass k+1 runs; the SSV kernels themselves are
 chained back to back, never side by side, so their event-timed durations stay clean.  All K
 passes are complete when the timed region ends; `config.ms_per_step_strictly_serial` shows
 the same K passes with one in flight.
 
-Workload at N = 1 is BASELINE.json configs[1] ("C2"): one pHMM of L = 1024 rows x
-100 Mbp of synthetic sequence (100,012,032 columns after padding to 12288),
-int8 scores, one kernel launch.  For N > 1 the run is WEAK-scaled: the database
-grows to N x 100,012,032 columns and is cut into N runs of whole 12288-column
-segments, one per rank (havac_amd/dist.py; a rank recomputes a left halo of
-rows-1 columns); every rank holds the whole packed sequence (N x 25 MB) in its
-own HBM, so no data-path collective is needed.
+Workloads (BASELINE.json configs):
+  c2 (default)  one pHMM of L = 1024 rows x 100 Mbp (100,012,032 columns after padding to 12288) per GPU; N > 1 is
+                WEAK-scaled: the database grows to N x 100,012,032 columns
+  c3            the 1000-model collection (lengths log-uniform in [50, 2000], 503,329 rows concatenated as
+                host/phmm/PhmmPreprocessor.cpp:9-31 does) x 10 Mbp (10,002,432 columns) per GPU; weak-scaled
+  c4            the same collection x 1 Gbp (81,381 segments = 1,000,009,728 columns) in all, STRONG-scaled: the
+                database is cut into N runs of whole segments, one per rank
+  c5            one pHMM of L = 20000 rows x 100 Mbp per GPU; weak-scaled
+The database is cut into N runs of whole 12288-column segments, one per rank (havac_amd/dist.py; a rank recomputes a
+left halo of rows-1 columns); every rank holds the whole packed sequence in its own HBM (C4: 250 MB), so there is no
+data-path collective.
 
-GCUPS = defined DP cells (columns x rows; padding outside the matrix is not
+GCUPS = defined DP cells (columns x rows; padding outside the matrix and halo recomputation are not
 counted) / wall time of the K timed steps, max over ranks.
 
-One JSON line is printed by rank 0; see README/DESIGN.md for the extra objects
-`roofline` (integer-VALU bound, with the HBM figures next to it) and
-`cpu_baseline` (the reference's softSsv, or our C restatement of it, on the
-host cores, on a bounded sample of the same workload).
+One JSON line is printed by rank 0; see DESIGN.md section 5 for the extra objects `roofline` (integer-VALU bound,
+with the HBM figures next to it; `traffic` = HBM bytes per launch measured by two rocprofv3 --pmc passes of a
+torch-free child of this script, started before this process touches the GPU) and `cpu_baseline` (the reference's
+softSsv, or our C restatement of it, on the host cores, on a bounded sample of the same workload).
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -45,9 +59,21 @@ sys.path.insert(0, ROOT)
 
 from havac_amd import synth  # noqa: E402
 
-COLUMNS_PER_GPU = 100_012_032          # 100 Mbp padded to 12288 (8139 segments)
-ROWS = 1024
+SEGMENT = synth.SEGMENT
 FPGA_GCUPS = 1739.0                    # reference README.md:4 (Alveo U50), BASELINE.md section 1
+
+# name -> (rows or None for the 1000-model collection, real symbols per unit, scaling); a unit is one GPU's share
+# for weak scaling and the whole database for strong scaling
+WORKLOADS = {
+    "c2": dict(rows=1024, real=100_000_000, scaling="weak", steps=20, warmup=3,
+               label="C2: 1 pHMM L=1024 x 100 Mbp (100,012,032 columns padded to 12288) per GPU"),
+    "c3": dict(rows=None, real=10_000_000, scaling="weak", steps=10, warmup=2,
+               label="C3: 1000-model collection (L 50-2000, 503,329 rows concatenated) x 10 Mbp (10,002,432 columns) per GPU"),
+    "c4": dict(rows=None, real=1_000_000_000, scaling="strong", steps=2, warmup=1,
+               label="C4: 1000-model collection (503,329 rows) x 1 Gbp (1,000,009,728 columns) sharded over the GPUs"),
+    "c5": dict(rows=20000, real=100_000_000, scaling="weak", steps=10, warmup=2,
+               label="C5: 1 pHMM L=20000 x 100 Mbp (100,012,032 columns) per GPU"),
+}
 
 # Roofline of ssv_diag_kernel.  Not HBM, not MFMA: the kernel is bound by
 # VALU issue.  Per DP cell the recurrence needs one 4:1 score select and one saturating add.  The select is served
@@ -65,10 +91,14 @@ OPS_PER_CELL = 1                        # one int16 saturating add per cell on t
 LDS_BYTES_PER_CELL = 2
 LDS_PEAK_TBS = 157.3
 HBM_PEAK_GBS = 8000.0
-# HBM bytes per launch of ssv_diag_kernel on the default workload, from the separate rocprofv3 --pmc
-# passes in profiles/r01f_pmc_c2.csv: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 with the gfx950 FETCH_SIZE
-# correction of MI355X_MICROARCH.md (uncalibrated for 8-byte-per-lane loads: an upper bound).
-PMC_TRAFFIC_C2_BYTES = (2 * 15039.3 + 8457.0) * 1024
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
 def plant_packed(packed: np.ndarray, consensus: np.ndarray, nreal: int, every=1_000_000, length=300, sub=0.15,
@@ -91,29 +121,112 @@ def plant_packed(packed: np.ndarray, consensus: np.ndarray, nreal: int, every=1_
     return planted
 
 
-def cpu_baseline(packed: np.ndarray, model: np.ndarray, gpu_hits: np.ndarray, cores: int, cols_per_core: int):
-    """Time the CPU path on a bounded sample (the first cores*cols_per_core columns, all rows) and
-    check that it finds exactly the hits the GPU reported for those columns."""
+def make_inputs(workload: str, world: int, rows_override=None, columns_override=None):
+    """-> (model int8 [rows,4], packed sequence, total columns, columns per GPU, planted homologs); same on every rank"""
+    w = WORKLOADS[workload]
+    if rows_override:
+        model, consensus = synth.dfam_like_model(rows_override, synth.SEED_MODEL)
+    elif w["rows"] is None:
+        model, consensus = synth.model_collection(synth.model_lengths(1000), synth.SEED_MODEL)
+    else:
+        model, consensus = synth.dfam_like_model(w["rows"], synth.SEED_MODEL)
+    unit = synth.padded_length(w["real"]) if not columns_override else columns_override
+    assert unit % SEGMENT == 0
+    ncols = unit if w["scaling"] == "strong" else unit * world
+    # the real symbols of every unit: what the padding to whole segments adds is symbol 0 ('A',
+    # host/sequence/SequencePreprocessor.cpp:41) at the very end of the database
+    nreal = ncols - (unit - w["real"]) * (1 if w["scaling"] == "strong" else world) if not columns_override else ncols
+    packed = synth.random_packed(ncols, synth.SEED_SEQUENCE)
+    planted = plant_packed(packed, consensus, nreal)
+    packed[nreal // 4:] = 0
+    return model, packed, ncols, (ncols // world if w["scaling"] == "strong" else unit), planted
+
+
+# ---- HBM traffic of the SSV kernel from the hardware counters -----------------------------------------------------
+def pmc_child(args):
+    """The program rocprofv3 --pmc runs: two passes of the workload through the handle API (ctypes + numpy only, no
+    torch: the profiler's library initialises the GPU before this program starts, so it must not re-exec anything)."""
+    from havac_amd.hw_client import HavacHwClient
+    model, packed, ncols, _, _ = make_inputs(args.workload, 1, args.rows, args.columns_per_gpu)
+    client = HavacHwClient(deviceIndex=0)
+    client.setHitCapacity(max(1 << 20, int(ncols * model.shape[0] * 1.2e-5)))
+    client.writeSequence(packed)
+    client.writePhmm(model)
+    for _ in range(2):
+        client.invokeHavacSsvAsync()
+        client.waitForHavacSsvAsync()
+    print("pmc child done", client.getNumHits(), flush=True)
+
+
+def measure_traffic(args):
+    """HBM bytes per launch of ssv_diag_kernel: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes (they do
+    not fit one pass on gfx950: MI355X_MICROARCH.md, PMC slots), traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 with the
+    guide's gfx950 FETCH_SIZE correction.  Must run before this process initialises the GPU.  -> (bytes or None, note)"""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    out = tempfile.mkdtemp(prefix="havac_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    values = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", counter.lower(), "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload]
+            if args.rows:
+                cmd += ["--rows", str(args.rows)]
+            if args.columns_per_gpu:
+                cmd += ["--columns-per-gpu", str(args.columns_per_gpu)]
+            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=args.pmc_timeout)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited {r.returncode}: {(r.stderr or r.stdout)[-300:]}"
+            per_dispatch = {}
+            for path in glob.glob(os.path.join(out, "**", f"*{counter.lower()}*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if "ssv_diag_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            per_dispatch[row["Dispatch_Id"]] = per_dispatch.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per_dispatch:
+                return None, f"no ssv_diag_kernel rows in the {counter} pass"
+            values[counter] = sum(per_dispatch.values()) / len(per_dispatch)
+    except subprocess.TimeoutExpired:
+        return None, "rocprofv3 --pmc pass timed out"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    traffic = (2.0 * values["FETCH_SIZE"] + values["WRITE_SIZE"]) * 1024.0
+    return traffic, (f"rocprofv3 --pmc, two passes of a child of this script: FETCH_SIZE {values['FETCH_SIZE']:.1f} KB "
+                     f"(x2: gfx950 correction, uncalibrated for 8-byte-per-lane loads), WRITE_SIZE {values['WRITE_SIZE']:.1f} KB "
+                     "per launch")
+
+
+# ---- CPU baseline -------------------------------------------------------------------------------------------------
+def cpu_baseline(packed: np.ndarray, model: np.ndarray, gpu_hits, cores: int, whole_list_limit_cells=6e12):
+    """Time the CPU path on a bounded sample -- the first columns of the database against the first `R` rows of the
+    model (all of them up to 20000 rows; a 4096-row prefix of a taller collection, which is self-contained because
+    a diagonal's score at row r depends on rows <= r only) -- and check that it finds exactly the records the GPU
+    reported for those cells.  gpu_hits: callable (col_lo, col_hi, row_hi) -> the GPU's records in that range."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import pyoracle as O
     nrows = model.shape[0]
+    R = nrows if nrows <= 20000 else 4096
+    cols_per_core = int(min(500_000, max(100_000, 6e9 / R))) // 4 * 4
     sample_cols = min(cores * cols_per_core, packed.size * 4)
     sample_cols -= sample_cols % 4
     sym = synth.unpack_2bit(packed[: sample_cols // 4])
+    sub = np.ascontiguousarray(model[:R])
     use_ref = O.ref_available()
     blocks = [(k * cols_per_core, min((k + 1) * cols_per_core, sample_cols)) for k in range(cores)]
     blocks = [b for b in blocks if b[0] < b[1]]
 
     def one(block):
         a, b = block
-        start = max(0, a - (nrows - 1))
+        start = max(0, a - (R - 1))
         if use_ref:     # the reference's own softSsvThreshold256 on [start, b), hits left of `a` dropped
-            h = O.ssv_reference(sym[start:b], model)
+            h = O.ssv_reference(sym[start:b], sub)
             rows, cols = O.unpack_hits(h)
             cols = cols + np.uint64(start)
             keep = cols >= np.uint64(a)
             return O.pack_hits(rows[keep], cols[keep])
-        return O.ssv_window(sym, model, a, b)
+        return O.ssv_window(sym, sub, a, b)
 
     O.lib()
     t0 = time.perf_counter()
@@ -121,34 +234,66 @@ def cpu_baseline(packed: np.ndarray, model: np.ndarray, gpu_hits: np.ndarray, co
         parts = list(pool.map(one, blocks))
     dt = time.perf_counter() - t0
     cpu_hits = O.device_order(np.concatenate(parts)) if parts else np.zeros(0, np.uint64)
-    _, gcols = O.unpack_hits(gpu_hits)
-    match = bool(np.array_equal(cpu_hits, O.device_order(gpu_hits[gcols < np.uint64(sample_cols)])))
-    cells = sample_cols * nrows
-    # second CPU figure: our AVX2 restatement (oracle.ssv_fast) over the WHOLE workload, which also lets the bench
-    # compare the complete hit list of the timed launch, not only the sample's
-    whole = synth.unpack_2bit(packed)
-    t1 = time.perf_counter()
-    fast_hits = O.ssv_fast(whole, model, nthreads=cores, cap=max(1 << 20, 2 * gpu_hits.size))
-    dt_fast = time.perf_counter() - t1
-    vectorised = {"value": round(whole.size * nrows / dt_fast / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
-                  "sample": f"the whole workload, {whole.size} columns x {nrows} rows, AVX2 int16 lanes, {dt_fast:.1f} s wall",
-                  "whole_hit_list_matches_gpu": bool(np.array_equal(fast_hits, gpu_hits))}
-    return {
+    match = bool(np.array_equal(cpu_hits, O.device_order(gpu_hits(0, sample_cols, R))))
+    cells = sample_cols * R
+    out = {
         "value": round(cells / dt / 1e9, 4), "unit": "GCUPS", "cores": len(blocks),
         "kind": "reference" if use_ref else "port",
-        "sample": f"first {sample_cols} columns x {nrows} rows of the same workload ({cells:.3g} cells, {dt:.1f} s wall, "
-                  f"{len(blocks)} threads each a column block with a {nrows - 1}-column left halo)",
-        "hits_match_gpu": match, "hits_in_sample": int(cpu_hits.size), "vectorised_port": vectorised,
+        "sample": f"first {sample_cols} columns x first {R} of {nrows} rows of the same workload ({cells:.3g} cells, {dt:.1f} s wall, "
+                  f"{len(blocks)} threads each a column block with a {R - 1}-column left halo)",
+        "hits_match_gpu": match, "hits_in_sample": int(cpu_hits.size),
     }
+    ncols = packed.size * 4
+    if ncols * nrows <= whole_list_limit_cells:
+        # second CPU figure: our AVX2 restatement (oracle.ssv_fast) over the WHOLE workload, which also lets the bench
+        # compare the complete hit list of the timed launch, not only the sample's
+        whole = synth.unpack_2bit(packed)
+        mine = gpu_hits(0, ncols, nrows)
+        t1 = time.perf_counter()
+        fast_hits = O.ssv_fast(whole, model, nthreads=cores, cap=max(1 << 20, mine.size + 1024))
+        dt_fast = time.perf_counter() - t1
+        out["vectorised_port"] = {
+            "value": round(whole.size * nrows / dt_fast / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
+            "sample": f"the whole workload, {whole.size} columns x {nrows} rows, AVX2 int16 lanes, {dt_fast:.1f} s wall",
+            "whole_hit_list_matches_gpu": bool(np.array_equal(fast_hits, mine))}
+    else:
+        # too many cells for any CPU route: one stretch of 5e6 columns over the whole height, every record
+        a = (ncols // 2) // SEGMENT * SEGMENT
+        b = a + 5_000_000
+        start = max(0, a - (nrows - 1)) // 4 * 4
+        stretch = synth.unpack_2bit(packed[start // 4: b // 4])
+        mine = gpu_hits(a, b, nrows)
+        t1 = time.perf_counter()
+        want = O.ssv_fast(stretch, model, nthreads=cores, cap=mine.size + (1 << 24))
+        rows_w, cols_w = O.unpack_hits(want)
+        keep = cols_w + np.uint64(start) >= np.uint64(a)
+        want = O.device_order(O.pack_hits(rows_w[keep], cols_w[keep] + np.uint64(start)))
+        dt_fast = time.perf_counter() - t1
+        out["vectorised_port"] = {
+            "value": round(stretch.size * nrows / dt_fast / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
+            "sample": f"columns [{a}, {b}) x all {nrows} rows with their {nrows - 1}-column halo, AVX2 int16 lanes, {dt_fast:.1f} s wall",
+            "records_in_stretch": int(want.size), "stretch_matches_gpu": bool(np.array_equal(want, mine))}
+    return out
+
+
+def launch_workers(args, argv):
+    """python bench.py --gpus N without a launcher: start N ranks as a child process (nothing in this process has
+    touched a GPU), pass their output through, exit with their code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=ROWS)
-    ap.add_argument("--columns-per-gpu", type=int, default=COLUMNS_PER_GPU)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--rows", type=int, default=0, help="probe: one Dfam-like model of this many rows instead of the workload's")
+    ap.add_argument("--columns-per-gpu", type=int, default=0, help="probe: this many columns (a multiple of 12288) per unit")
     ap.add_argument("--pipeline-depth", type=int, default=0,
                     help="passes in flight (own context, hit buffer and stream each): the ordering / gather of pass k "
                          "overlaps the SSV kernel of pass k+1; the SSV kernels stay back to back.  1 = strictly serial; "
@@ -156,24 +301,41 @@ def main():
                          "records next to the following kernel slows that kernel by more than it hides "
                          "(C3 shape: 303 vs 267 ms per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cols-per-core", type=int, default=500_000)
-    ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per launch of the SSV kernel from a separate rocprofv3 --pmc pass (profiles/)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--pmc-timeout", type=int, default=240)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    w = WORKLOADS[args.workload]
+    if args.steps is None:
+        args.steps = w["steps"]
+    if args.warmup is None:
+        args.warmup = w["warmup"]
+    if args.pmc_child:
+        return pmc_child(args)
 
-    import torch
-    import torch.distributed as dist
-    from havac_amd.dist import ShardedSsv
-    from havac_amd.ssv import shard_cells
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_workers(args, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world
+    # HAVAC_BENCH_FORCE_DIST=1: rehearse the N > 1 code path (process group, gather, barrier, all-reduce) with the
+    # ranks there are, even one -- the only way to run it over RCCL on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("HAVAC_BENCH_FORCE_DIST") == "1"
+
+    # HBM traffic from the counters, by a child under rocprofv3, BEFORE this process initialises the GPU
+    traffic, traffic_note = None, "not measured (N > 1, --no-pmc, or a pass of more than 1e13 cells)"
+    model, packed, ncols, cols_per_gpu, planted = make_inputs(args.workload, world, args.rows, args.columns_per_gpu)
+    nrows = model.shape[0]
+    if world == 1 and not use_dist and not args.no_pmc and ncols * nrows <= 1e13:
+        traffic, traffic_note = measure_traffic(args)
+
+    import torch
+    import torch.distributed as dist
+    from havac_amd.dist import ShardedSsv
+    from havac_amd.ssv import shard_cells, shard_columns
+
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # HAVAC_BENCH_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the N>1 path on a 1-GPU box
@@ -183,34 +345,24 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % ndev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    # HAVAC_BENCH_FORCE_DIST=1: rehearse the N > 1 code path (process group, gather, barrier, all-reduce) with the
-    # ranks there are, even one -- the only way to run it over RCCL on a 1-GPU box
-    use_dist = world > 1 or os.environ.get("HAVAC_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
 
-    assert args.columns_per_gpu % synth.SEGMENT == 0
-    ncols = args.columns_per_gpu * world
-    nrows = args.rows
-
-    # ---- synthetic inputs (same on every rank: same seeds) -------------------
-    model, consensus = synth.dfam_like_model(nrows, synth.SEED_MODEL)
-    packed = synth.random_packed(ncols, synth.SEED_SEQUENCE)
-    nreal = ncols - 12_032 * world if args.columns_per_gpu == COLUMNS_PER_GPU else ncols
-    planted = plant_packed(packed, consensus, nreal)
-    packed[nreal // 4:] = 0                      # padding is symbol 0 ('A'), SequencePreprocessor.cpp:41
     d_seq = torch.from_numpy(packed).to(device)
     d_phmm = torch.from_numpy(model.reshape(-1)).to(device)
 
-    hit_capacity = max(1 << 20, int(args.columns_per_gpu * nrows * 4e-5))
-    depth = args.pipeline_depth if args.pipeline_depth > 0 else (3 if args.columns_per_gpu * nrows <= 1e12 else 1)
-    engine = ShardedSsv(hit_capacity, device, depth=depth, gather_when_alone=use_dist)
     my_cells = shard_cells(ncols, nrows, rank, world)
     total_cells = ncols * nrows
+    # records per cell: 1.0e-5 on C2, 0.9e-5 on the collection
+    hit_capacity = max(1 << 20, int(my_cells * (4e-5 if my_cells <= 1e13 else 1.2e-5)))
+    depth = args.pipeline_depth if args.pipeline_depth > 0 else (3 if my_cells <= 1e12 else 1)
+    engine = ShardedSsv(hit_capacity, device, depth=depth, gather_when_alone=use_dist)
 
     def fence():
         if use_dist:
@@ -233,16 +385,19 @@ def main():
     # set-up, not warm-up: one pass through every slot so that each context has its sort buffers before anything is
     # timed (a slot first used inside the timed region would pay a hipMalloc there when --warmup < --pipeline-depth)
     run_steps(engine, depth)
-    run_steps(engine, args.warmup)
+    run_steps(engine, max(0, args.warmup - depth))
+    engine.gather_times()
+    engine.gather_ms = []
     fence()
     t0 = time.perf_counter()
     (merged, found), kernel_ms = run_steps(engine, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    if rank == 0 and merged is not None:
-        merged = merged.clone()
+    gather_ms = list(engine.gather_times())
     serial_ms, serial_timings = None, kernel_ms
     if depth > 1:       # the same steps strictly one after the other, for the record (not `value`)
+        if rank == 0 and merged is not None:
+            merged = merged.clone()
         serial = ShardedSsv(hit_capacity, device, depth=1, gather_when_alone=use_dist)
         run_steps(serial, 2)
         fence()
@@ -251,10 +406,19 @@ def main():
         fence()
         serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
         serial.close()
+    per_rank = None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        lo, hi = shard_columns(ncols, rank, world)
+        h = min(nrows - 1, lo)
+        halo = h * (h + 1) // 2 + (nrows - 1 - h) * lo     # cells left of its columns a rank recomputes: sum over rows p of min(p, lo)
+        mine = {"rank": rank, "device": torch.cuda.get_device_name(device), "columns": [lo, hi], "records": int(found),
+                "kernel_ms": round(float(np.mean([k[0] for k in kernel_ms])), 4), "halo_cells": int(halo),
+                "gather_ms": round(float(np.mean(gather_ms)), 4) if gather_ms else None}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -262,26 +426,28 @@ def main():
         ssv_ms = float(np.mean([k[0] for k in kernel_ms]))
         enq_ms = float(np.mean([k[1] for k in serial_timings]))   # of the strictly serial passes: no queueing in it
         nhits = int(merged.numel())
-        hits_np = merged.cpu().numpy().view(np.uint64)
         # algorithmic HBM bytes of this rank's launch: its share of the packed sequence once, the
         # model once (4 B/row), 8 B per hit
         algo_bytes = ncols / 4 / world + 4 * nrows + 8 * found
         kernel_s = ssv_ms / 1e3
         achieved_tiops = my_cells * OPS_PER_CELL / kernel_s / 1e12
+        custom = bool(args.rows or args.columns_per_gpu)
         out = {
             "metric": "GCUPS (billion SSV cells/s); hit-list bit-exact vs softSsv",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": w["scaling"],
             "vs_baseline": round(gcups / FPGA_GCUPS, 3), "dtype": "i16",
             "data": "synthetic",
             "config": {
-                "workload": (("C2: " if (nrows == ROWS and args.columns_per_gpu == COLUMNS_PER_GPU) else "custom: ") +
-                             f"1 pHMM L={nrows} x {args.columns_per_gpu} columns per GPU "
-                             "(C2 = 100 Mbp padded to 12288), int8 SSV, one kernel launch per step"),
-                "rows": nrows, "columns": ncols, "cells_per_step": total_cells, "hits_per_step": nhits,
-                "planted_homologs": planted, "passes_in_flight": depth,
+                "workload": (("custom probe on " if custom else "") + w["label"] +
+                             (f" [--rows {args.rows}]" if args.rows else "") +
+                             (f" [--columns-per-gpu {args.columns_per_gpu}]" if args.columns_per_gpu else "") +
+                             "; int8 SSV, one kernel launch per step and GPU"),
+                "rows": nrows, "columns": ncols, "columns_per_gpu": cols_per_gpu, "cells_per_step": total_cells,
+                "hits_per_step": nhits, "planted_homologs": planted, "passes_in_flight": depth,
                 "ms_per_step_strictly_serial": None if serial_ms is None else round(serial_ms, 4),
-                "parallelism": f"column-sharded x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} gather of hit records to rank 0" if world > 1 else ""),
+                "value_strictly_serial": None if serial_ms is None else round(total_cells / serial_ms / 1e6, 2),
+                "parallelism": f"column-sharded x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} gather of hit records to rank 0" if use_dist else ""),
                 "baseline": "1739 GCUPS = reference README.md:4, 1x Alveo U50 FPGA",
             },
             "kernel": {"name": "ssv_diag_kernel", "avg_ms": round(ssv_ms, 4), "enqueue_to_ordered_ms": round(enq_ms, 4),
@@ -294,8 +460,7 @@ def main():
                 # SURVEY.md 8d wrote the VALU fraction as GCUPS*1e9*2/3.93e13 (select AND add on the VALU, 32-bit lanes);
                 # it exceeds 1 here because the select is served by LDS
                 "frac_by_survey_8d_formula": round(my_cells / kernel_s * 2 / 3.93e13, 4),
-                "traffic": args.traffic_bytes if args.traffic_bytes is not None else (
-                    PMC_TRAFFIC_C2_BYTES if (world == 1 and nrows == ROWS and args.columns_per_gpu == COLUMNS_PER_GPU) else None),
+                "traffic": None if traffic is None else round(traffic, 1), "traffic_source": traffic_note,
                 "lds": {"bound": "lds", "achieved": round(my_cells * LDS_BYTES_PER_CELL / kernel_s / 1e12, 2),
                         "peak": LDS_PEAK_TBS, "unit": "TB/s (ds_read_b64, 2 B per cell)",
                         "frac": round(my_cells * LDS_BYTES_PER_CELL / kernel_s / 1e12 / LDS_PEAK_TBS, 4)},
@@ -304,9 +469,39 @@ def main():
                         "algorithmic_bytes_per_launch": int(algo_bytes)},
             },
         }
+        if use_dist:
+            out["distributed"] = {
+                "world": dist.get_world_size(), "backend": dist.get_backend(),
+                "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
+                "gather": "all_gather of the counts + grouped send/recv of exactly count[r] records into one buffer on rank 0",
+                "gather_ms_rank0": round(float(np.mean(gather_ms)), 4) if gather_ms else None,
+                "per_rank": per_rank,
+            }
         if world == 1 and not args.no_cpu_baseline:
             cores = min(16, len(os.sched_getaffinity(0)))   # a 1-GPU box's CPU share
-            out["cpu_baseline"] = cpu_baseline(packed, model, hits_np, cores, args.cpu_cols_per_core)
+
+            def first_of_segment(seg):
+                """index of the first record of segment >= seg: the list is in device order, segment-major"""
+                lo_i, hi_i = 0, nhits
+                while lo_i < hi_i:
+                    mid = (lo_i + hi_i) // 2
+                    if ((int(merged[mid].item()) >> 14) & 0x3FFFFFF) < seg:
+                        lo_i = mid + 1
+                    else:
+                        hi_i = mid
+                return lo_i
+
+            def gpu_hits(col_lo, col_hi, row_hi):
+                """the GPU's records with col_lo <= column < col_hi and row < row_hi: the segments that hold those
+                columns are one contiguous slice of the ordered list; the rest is filtered on the device"""
+                part = merged[first_of_segment(col_lo // SEGMENT): first_of_segment((col_hi + SEGMENT - 1) // SEGMENT)]
+                cols = ((part >> 14) & 0x3FFFFFF) * SEGMENT + (part & 0x3FFF)
+                keep = (cols >= col_lo) & (cols < col_hi)
+                if row_hi < nrows:
+                    keep &= ((part >> 40) & 0xFFFFFF) < row_hi
+                return part[keep].cpu().numpy().view(np.uint64)
+
+            out["cpu_baseline"] = cpu_baseline(packed, model, gpu_hits, cores)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

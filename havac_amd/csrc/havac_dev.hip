@@ -712,6 +712,10 @@ extern "C" int havac_dev_num_hits64(havac_dev* d, uint64_t* count) {
     if (!d->has_run) { d->err = "num hits was not set by the client!"; return HAVAC_E_RUNTIME; }   // HavacHwClient.cpp:181-183
     if (!d->finished) { int s = havac_dev_wait(d, 0); if (s < 0) return s; }
     if (d->failed) return d->overflowed ? HAVAC_E_HIT_OVERFLOW : HAVAC_E_RUNTIME;
+    if (d->aborted) {       // the sweep stopped part-way: whatever it had queued is not a hit list
+        d->err = "the run was aborted: it has no hit list";
+        return HAVAC_E_LOGIC;
+    }
     *count = d->found;
     return HAVAC_OK;
 }

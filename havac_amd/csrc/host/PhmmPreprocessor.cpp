@@ -1,9 +1,23 @@
 // PhmmPreprocessor.cpp -- restates host/phmm/PhmmPreprocessor.cpp:9-31.
 #include "PhmmPreprocessor.hpp"
 
+#include <stdexcept>
+#include <string>
+
 #include "PhmmReprojection.h"
 
+// The tables are [row][A,C,G,T] (host/phmm/PhmmPreprocessor.cpp:15 allocates rows * 4), but the projection writes
+// cardinality * rows scores (PhmmReprojection.cpp:117-118): an `ALPH amino` model (20 per row) would run past the
+// buffer.  The reference has the same flaw and no check; here such a file is an error.
+static void requireNucleotideModels(const P7HmmList *phmmList) {
+    for (uint32_t i = 0; i < phmmList->count; i++)
+        if (p7HmmGetAlphabetCardinality(&phmmList->phmms[i]) != 4)
+            throw std::runtime_error("model " + std::to_string(i) + " of the phmm file is not a nucleotide model "
+                                     "(only nucleotide phmms with 4 scores/position are supported).");
+}
+
 PhmmPreprocessor::PhmmPreprocessor(P7HmmList *phmmList, const float desiredPvalue) {
+    requireNucleotideModels(phmmList);
     for (uint32_t i = 0; i < phmmList->count; i++) rows_ += phmmList->phmms[i].header.modelLength;
     data_ = std::make_shared<std::vector<int8_t>>((size_t)rows_ * 4);
     size_t at = 0;
@@ -14,6 +28,7 @@ PhmmPreprocessor::PhmmPreprocessor(P7HmmList *phmmList, const float desiredPvalu
 }
 
 PhmmPreprocessor::PhmmPreprocessor(P7HmmList *phmmList, const float desiredPvalue, bool boundaryMode) {
+    requireNucleotideModels(phmmList);
     const uint32_t gap = boundaryMode ? 2u : 0u;
     for (uint32_t i = 0; i < phmmList->count; i++) {
         modelStarts_.push_back(rows_);

@@ -208,8 +208,16 @@ int havac_host_project_hmm(const char *path, float p, int8_t *out, uint64_t cap,
     P7HmmReturnCode rc = readP7Hmm(path, &list);
     if (rc == p7HmmAllocationFailure) return HAVAC_E_NOMEM;
     if (rc != p7HmmSuccess) return HAVAC_E_RUNTIME;
-    PhmmPreprocessor pre(&list, p);
-    auto data = pre.getProcessedPhmmData();
+    std::shared_ptr<std::vector<int8_t>> data;
+    try {
+        data = PhmmPreprocessor(&list, p).getProcessedPhmmData();
+    } catch (const std::bad_alloc &) {
+        p7HmmListDealloc(&list);
+        return HAVAC_E_NOMEM;
+    } catch (const std::exception &) {          // a model that is not a nucleotide model
+        p7HmmListDealloc(&list);
+        return HAVAC_E_ARGUMENT;
+    }
     if (nbytes) *nbytes = data->size();
     if (nmodels) *nmodels = list.count;
     for (uint32_t i = 0; lengths && i < list.count && i < lengths_cap; i++) lengths[i] = list.phmms[i].header.modelLength;

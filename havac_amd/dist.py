@@ -2,7 +2,7 @@
 
 A cell depends only on its own diagonal, so rank r sweeps
 the diagonals that reach its columns from their start (a left halo of nrows-1
-columns is recomputed: C4, sum L = 1e6 over 1.25e8 columns per rank, 0.4 % extra
+columns is recomputed: C4, sum L = 5e5 over 1.25e8 columns per rank, 0.2 % extra
 work) and reports only the hits inside its columns.  No data-path collective.
 Each rank orders its own records; because the shards are runs of whole segments,
 the lists concatenated in rank order ARE the reference's device order, so the
@@ -10,41 +10,72 @@ only exchange is the gather of the records to rank 0 (RCCL over xGMI when the
 backend is "nccl"; the same code runs over gloo on CPU tensors in the tests) and
 rank 0 never sorts.  The reference has no multi-device path at all
 (host/Havac.hpp:51: one deviceIndex per object).
+
+The gather is variable-length: after one all_gather of the per-rank counts
+(8 B per rank) every rank r > 0 sends exactly its `count[r]` records and rank 0
+receives each list straight into ONE buffer of sum(count) records at the
+exclusive-scan offset of its rank (grouped point-to-point: ncclSend/ncclRecv
+inside one ncclGroup over RCCL).  Nothing is padded to the largest list and
+nothing is concatenated afterwards, so rank 0's extra memory is sum(count) * 8 B
+(C4: 4.5e9 records = 36 GB; the padded gather + torch.cat of round 1 needed
+more than twice that).  A rank whose pass failed (hit-buffer overflow, HIP
+error) reports the count -1: the collective still runs on every rank and every
+rank raises afterwards, so no rank is left waiting inside a collective.
 """
 from __future__ import annotations
 
 import torch
 import torch.distributed as dist
 
+FAILED = -1      # count reported by a rank whose pass raised
 
-def gather_hits(local_hits: torch.Tensor, local_count: int, group=None):
+
+class ShardFailure(RuntimeError):
+    """Some rank's pass failed; raised on EVERY rank after the count exchange."""
+
+
+def gather_hits(local_hits: torch.Tensor, local_count: int, group=None, out: torch.Tensor | None = None):
     """All ranks call this with their own records (int64 view of the packed u64, first
-    `local_count` valid).  Returns (records concatenated in rank order, per-rank counts) on
-    rank 0 and (None, counts) elsewhere.  Two collectives: an all_gather of the counts
-    (8 B per rank), then a gather to rank 0 of the records padded to the largest count
-    (payload is KB..MB per rank)."""
+    `local_count` valid; `local_count` = FAILED if this rank's pass raised).  Returns
+    (records concatenated in rank order, per-rank counts) on rank 0 and (None, counts)
+    elsewhere.  `out`: optional receive buffer on rank 0 (used when it is large enough)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     out_dev = local_hits.device
     # gloo (CPU rehearsals and the tests) moves host tensors; nccl = RCCL moves device tensors over xGMI
     dev = torch.device("cpu") if dist.get_backend(group) == "gloo" else out_dev
-    capacity = local_hits.numel()
-    local_hits = local_hits.to(dev) if dev != out_dev else local_hits
-    mine = torch.tensor([local_count], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, mine, group=group)
-    counts = torch.cat(counts).tolist()          # one device-to-host sync for all ranks' counts
-    biggest = max(counts)
-    if biggest == 0:
-        return (local_hits[:0].to(out_dev) if rank == 0 else None), counts
-    if biggest > capacity:
-        raise ValueError("ranks must use hit buffers of one capacity (a rank reported more records than fit here)")
-    padded = local_hits[:biggest]                  # no copy: records beyond local_count are ignored by rank 0
-    parts = [torch.empty(biggest, dtype=local_hits.dtype, device=dev) for _ in range(world)] if rank == 0 else None
-    dist.gather(padded, parts, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if dev != out_dev:
+        local_hits = local_hits[: max(local_count, 0)].to(dev)
+    counts_t = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts_t, torch.tensor([local_count], dtype=torch.int64, device=dev), group=group)
+    counts = counts_t.tolist()       # the one host wait of the gather; with passes in flight it waits on the slot's
+    #                                  stream only, while the next pass's kernel is already running on another
+    bad = [r for r, c in enumerate(counts) if c < 0]
+    if bad:
+        raise ShardFailure(f"the pass failed on rank(s) {bad}; no records were gathered")
+    total = sum(counts)
+    root = dist.get_global_rank(group, 0) if group is not None else 0
     if rank != 0:
+        if local_count:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local_hits[:local_count], root, group=group)]):
+                w.wait()
         return None, counts
-    return torch.cat([p[:c] for p, c in zip(parts, counts)]).to(out_dev), counts
+    if out is not None and out.device == dev and out.numel() >= total:
+        merged = out[:total]
+    else:
+        merged = torch.empty(total, dtype=local_hits.dtype, device=dev)
+    ops, offset = [], counts[0]
+    for r in range(1, world):
+        if counts[r]:
+            peer = dist.get_global_rank(group, r) if group is not None else r
+            ops.append(dist.P2POp(dist.irecv, merged[offset: offset + counts[r]], peer, group=group))
+        offset += counts[r]
+    works = dist.batch_isend_irecv(ops) if ops else []
+    if counts[0]:
+        merged[: counts[0]].copy_(local_hits[: counts[0]])
+    for w in works:
+        w.wait()
+    return (merged.to(out_dev) if dev != out_dev else merged), counts
 
 
 class _Slot:
@@ -54,6 +85,8 @@ class _Slot:
         self.hits = torch.empty(hit_capacity, dtype=torch.int64, device=device)
         self.stream = torch.cuda.Stream(device) if own_stream else None
         self.kernel_done = None          # recorded behind the SSV kernel of the pass in flight
+        self.merged = None               # rank 0: receive buffer of the gather, grown on demand and kept
+        self.gather_events = None        # (before, after) on the stream the gather ran on
 
 
 class ShardedSsv:
@@ -63,7 +96,10 @@ class ShardedSsv:
     ``submit`` enqueues a pass, ``collect`` finishes the oldest one.  While the host waits for pass k's hit count,
     orders its records and (N > 1) gathers them over RCCL, the SSV kernel of pass k+1 is already running.  The SSV
     kernels themselves are kept back to back, never side by side (pass k+1 waits for the kernel of pass k), so a
-    kernel's event-timed duration stays the duration of that kernel alone."""
+    kernel's event-timed duration stays the duration of that kernel alone.
+
+    The records ``collect`` returns live in the slot's receive buffer (world > 1) or hit buffer (world == 1): they
+    are valid until that slot is submitted again, and the caller's current stream has been made to wait for them."""
 
     def __init__(self, hit_capacity: int, device: torch.device, depth: int = 1, back_to_back: bool = True,
                  gather_when_alone: bool = False):
@@ -79,6 +115,8 @@ class ShardedSsv:
         self.last_kernel_done = None
         self.ctx = self.slots[0].ctx      # the context of the most recently collected pass (for last_ms)
         self.hits = self.slots[0].hits
+        self.gather_ms = []               # device time of each gather on this rank (filled by gather_times())
+        self._timed = []
 
     def submit(self, d_seq: torch.Tensor, nsymbols: int, d_phmm: torch.Tensor, nrows: int):
         if len(self.in_flight) == len(self.slots):
@@ -99,18 +137,47 @@ class ShardedSsv:
         self.next_slot = (self.next_slot + 1) % len(self.slots)
 
     def collect(self):
-        """-> (records on rank 0 in device order or None, hits found by this rank) of the oldest pass in flight"""
+        """-> (records on rank 0 in device order or None, hits found by this rank) of the oldest pass in flight.
+        If the pass failed on any rank, every rank raises (this rank's own error, or ShardFailure)."""
         slot = self.slots[self.in_flight.pop(0)]
-        found = slot.ctx.finish()
+        error = None
+        try:
+            found = slot.ctx.finish()
+        except Exception as e:            # still take part in the collectives below: the other ranks are in them
+            error, found = e, FAILED
         self.ctx, self.hits = slot.ctx, slot.hits
         if self.world == 1 and not self.gather_when_alone:
+            if error is not None:
+                raise error
             return slot.hits[:found], found
-        if slot.stream is None:
-            merged, _ = gather_hits(slot.hits, found)
-        else:
-            with torch.cuda.stream(slot.stream):
-                merged, _ = gather_hits(slot.hits, found)
+        current = torch.cuda.current_stream(self.device)
+        stream = slot.stream if slot.stream is not None else current
+        try:
+            with torch.cuda.stream(stream):
+                before, after = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                before.record(stream)
+                merged, counts = gather_hits(slot.hits, found, out=slot.merged)
+                after.record(stream)
+        except ShardFailure:
+            if error is not None:
+                raise error
+            raise
+        self._timed.append((before, after))
+        if merged is not None:
+            if slot.merged is None or merged.numel() > slot.merged.numel():
+                slot.merged = merged
+            if stream is not current:      # hand the records over to the caller's stream
+                current.wait_stream(stream)
+                merged.record_stream(current)
         return merged, found
+
+    def gather_times(self):
+        """device milliseconds of every gather so far (synchronises the events)"""
+        for before, after in self._timed:
+            after.synchronize()
+            self.gather_ms.append(before.elapsed_time(after))
+        self._timed = []
+        return self.gather_ms
 
     def run(self, d_seq: torch.Tensor, nsymbols: int, d_phmm: torch.Tensor, nrows: int):
         """one pass, start to end -> (records on rank 0 in device order or None, hits found by this rank)"""

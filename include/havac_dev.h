@@ -149,8 +149,9 @@ int havac_dev_wait(havac_dev *dev, uint32_t timeout_ms);
 int havac_dev_abort(havac_dev *dev);
 
 /* HavacHwClient::getNumHits / getHitList  host/HavacHwClient.cpp:172-202.
- * Valid after a completed run.  read_hits copies min(n, count) records in
- * device order. */
+ * Valid after a completed run (HAVAC_E_LOGIC after an aborted one: a sweep
+ * that was stopped part-way has no hit list).  read_hits copies min(n, count)
+ * records in device order. */
 int havac_dev_num_hits(havac_dev *dev, uint32_t *count);
 /* The same with 64-bit counts: several GPUs behind one handle can hold more than 2^32 - 1 records (C4: 4.5e9);
  * havac_dev_num_hits returns HAVAC_E_HIT_OVERFLOW then instead of a truncated count. */

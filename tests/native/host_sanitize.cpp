@@ -3,6 +3,7 @@
 // packers, the reverse-strand builder, the patch collector, the position lookup and both model preprocessors.
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -47,6 +48,13 @@ int main(int argc, char **argv) {
             const int rc = readP7Hmm(path.c_str(), &list);
             std::printf("%s: rc %d\n", path.c_str(), rc);
             if (rc == p7HmmSuccess) {
+                try {
+                    PhmmPreprocessor probe(&list, 0.02f);
+                } catch (const std::exception &e) {
+                    std::printf("  rejected: %s\n", e.what());
+                    p7HmmListDealloc(&list);
+                    continue;
+                }
                 PhmmPreprocessor plain(&list, 0.02f);
                 PhmmPreprocessor separated(&list, 0.02f, true);
                 std::printf("  %u models, %zu bytes, separated %zu bytes\n", list.count, plain.getProcessedPhmmData()->size(),

@@ -220,6 +220,48 @@ def test_c4_shape_one_shard_of_eight(torch_dev, oracle):
     assert np.array_equal(got, whole_list(oracle, packed, model, lo, hi))  # the shard's 3.75e11 cells, every record
 
 
+def test_c4_full_height_one_shard_of_eight(torch_dev, oracle):
+    """Config C4 as BASELINE.json states it, as far as one GPU goes: the 1 Gbp database x the 1000-model collection
+    (503,329 rows), the columns rank 5 of an 8-GPU node owns -- 1.25e8 columns, 6.3e13 cells, 5.6e8 records -- and
+    every record of two 1.5e7-column stretches of it (the shard's left edge, where the halo ends, and its middle;
+    6.7e7 records each) compared with the checker.  The other seven ranks run the same code on other columns."""
+    torch, dev = torch_dev
+    from havac_amd.ssv import SsvContext, shard_columns
+    n = 81_381 * synth.SEGMENT                                  # 1,000,009,728 columns
+    model, cons = synth.model_collection(synth.model_lengths(1000), 2101)
+    nrows = model.shape[0]
+    assert nrows > 500_000
+    packed = synth.random_packed(n, 777)
+    lo, hi = shard_columns(n, 5, 8)
+    d_seq = torch.from_numpy(packed).to(dev)
+    d_phmm = torch.from_numpy(model.reshape(-1)).to(dev)
+    cap = 1 << 30
+    hits = torch.empty(cap, dtype=torch.int64, device=dev)
+    ctx = SsvContext()
+    ctx.enqueue(d_seq.data_ptr(), n, d_phmm.data_ptr(), nrows, hits.data_ptr(), cap, 5, 8, 0,
+                torch.cuda.current_stream(dev).cuda_stream)
+    found = ctx.finish()
+    ctx.close()
+    assert found > 500_000_000
+    rec = hits[:found]
+    cols = ((rec >> 14) & 0x3FFFFFF) * synth.SEGMENT + (rec & 0x3FFF)
+    assert int(cols.min()) >= lo and int(cols.max()) < hi
+    assert bool((rec[1:] != rec[:-1]).all())                                  # no record twice
+    for a in (lo, (lo + hi) // 2 // 4 * 4):
+        b = a + 15_000_000
+        mine = rec[(cols >= a) & (cols < b)].cpu().numpy().view(np.uint64)
+        assert np.array_equal(mine, oracle.device_order(mine))             # a slice of the device-ordered list
+        start = max(0, a - (nrows - 1)) // 4 * 4
+        sym = synth.unpack_2bit(packed[start // 4: b // 4])
+        want = oracle.ssv_fast(sym, model, nthreads=16, cap=mine.size + (1 << 24))
+        rows_w, cols_w = oracle.unpack_hits(want)
+        keep = cols_w + np.uint64(start) >= np.uint64(a)
+        want = oracle.device_order(oracle.pack_hits(rows_w[keep], cols_w[keep] + np.uint64(start)))
+        assert mine.size > 60_000_000 and np.array_equal(mine, want)
+    del hits, rec, cols
+    torch.cuda.empty_cache()
+
+
 def test_passes_in_flight_give_the_same_lists(torch_dev, oracle):
     """ShardedSsv with several passes in flight (bench.py's default): six different problems submitted through
     three slots come back in submission order, each equal to its own oracle list."""
