@@ -234,6 +234,21 @@ float havac_host_scaling_factor(float mu, float lambda, uint32_t max_length, uin
     return findThreshold256ScalingFactor(&h, p);
 }
 
+int havac_host_project_model(float mu, float lambda, uint32_t max_length, uint32_t model_length, float p,
+                             const float *emissions, int8_t *out) {
+    if (!emissions || !out || model_length == 0) return HAVAC_E_ARGUMENT;
+    P7Hmm h;
+    std::memset(&h, 0, sizeof h);
+    h.header.alphabet = P7HmmReaderAlphabetDna;
+    h.stats.msvGumbelMu = mu; h.stats.msvGumbelLambda = lambda;
+    h.header.maxLength = max_length; h.header.modelLength = model_length;
+    h.model.matchEmissionScores = const_cast<float *>(emissions);
+    p7HmmProjectForThreshold256(&h, p, out);
+    return HAVAC_OK;
+}
+
+double havac_host_gumbel_invsurv(double p, double mu, double lambda) { return esl_gumbel_invsurv(p, mu, lambda); }
+
 float havac_host_project_score(float s, float m) { return emissionScoreToProjectedScore(s, m); }
 
 int havac_host_resolve_hits(const char *fasta, const char *hmm, const uint64_t *raw, uint32_t nraw, uint64_t *sp,

@@ -48,6 +48,8 @@ HOST_SIGNATURES = {
                                          C.POINTER(C.c_uint32), _vp, C.c_uint32]),
     "havac_host_scaling_factor": (C.c_float, [C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_float]),
     "havac_host_project_score": (C.c_float, [C.c_float, C.c_float]),
+    "havac_host_project_model": (C.c_int, [C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_float, _vp, _vp]),
+    "havac_host_gumbel_invsurv": (C.c_double, [C.c_double, C.c_double, C.c_double]),
     "havac_host_resolve_hits": (C.c_int, [C.c_char_p, C.c_char_p, _vp, C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint32,
                                           C.POINTER(C.c_uint32)]),
     "havac_host_merge_windows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32,
@@ -260,6 +262,20 @@ def project_hmm(path: str, p_value: float = 0.02):
 
 def scaling_factor(mu, lam, max_length, model_length, p_value) -> float:
     return float(load_host().havac_host_scaling_factor(mu, lam, max_length, model_length, p_value))
+
+
+def project_model(mu, lam, max_length, emissions, p_value) -> np.ndarray:
+    """p7HmmProjectForThreshold256 on explicit parameters: emissions [L,4] float32 file values -> int8 [L,4]."""
+    em = np.ascontiguousarray(emissions, dtype=np.float32)
+    out = np.empty(em.shape, dtype=np.int8)
+    rc = load_host().havac_host_project_model(mu, lam, int(max_length), em.shape[0], p_value, em.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise_for(rc, "bad argument to havac_host_project_model")
+    return out
+
+
+def gumbel_invsurv(p, mu, lam) -> float:
+    return float(load_host().havac_host_gumbel_invsurv(p, mu, lam))
 
 
 def project_score(emission_score, multiplier) -> float:

@@ -60,6 +60,12 @@ int havac_host_pack_fasta(const char *fasta_path, int64_t seed, uint8_t *out, ui
 int havac_host_project_hmm(const char *hmm_path, float p_value, int8_t *out, uint64_t cap, uint64_t *nbytes,
                            uint32_t *nmodels, uint32_t *model_lengths, uint32_t lengths_cap);
 
+/* p7HmmProjectForThreshold256 on explicit parameters (PhmmReprojection.cpp:109-145): `emissions` = model_length x 4
+ * match-emission file values (-ln p, +inf for '*'), `out` = model_length x 4 int8. */
+int havac_host_project_model(float mu, float lambda, uint32_t max_length, uint32_t model_length, float p_value,
+                             const float *emissions, int8_t *out);
+/* esl_gumbel_invsurv (PhmmReprojection.cpp:15-31). */
+double havac_host_gumbel_invsurv(double p, double mu, double lambda);
 /* findThreshold256ScalingFactor on explicit parameters (PhmmReprojection.cpp:36-64). */
 float havac_host_scaling_factor(float mu, float lambda, uint32_t max_length, uint32_t model_length, float p_value);
 /* emissionScoreToProjectedScore (PhmmReprojection.cpp:90-107). */
