@@ -86,6 +86,7 @@ void shard_tiles(const Tiling& t, uint32_t nrows, uint64_t col_begin, uint64_t c
 struct havac_ssv_ctx {
     int device = 0;
     uint32_t* rows8 = nullptr; size_t rows8_rows = 0;   // padded copy of the model
+    uint32_t* chunk_flags = nullptr; size_t chunk_flag_words = 0;   // one bit per 32-row chunk: hit test every four steps allowed
     const uint16_t* pair_mask = nullptr;                // optional separator bitmap (boundary mode), caller-owned
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     uint64_t* sort_alt = nullptr; size_t sort_alt_count = 0;
@@ -125,6 +126,7 @@ extern "C" int havac_ssv_ctx_create(havac_ssv_ctx** out) {
 extern "C" void havac_ssv_ctx_destroy(havac_ssv_ctx* c) {
     if (!c) return;
     if (c->rows8) (void)hipFree(c->rows8);
+    if (c->chunk_flags) (void)hipFree(c->chunk_flags);
     if (c->sort_tmp) (void)hipFree(c->sort_tmp);
     if (c->sort_alt) (void)hipFree(c->sort_alt);
     if (c->d_count) (void)hipFree(c->d_count);
@@ -200,6 +202,13 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         HIP_TRY(c->err, hipMalloc(&c->rows8, (size_t)model_words * sizeof(uint32_t)));
         c->rows8_rows = model_words;
     }
+    const uint32_t flag_words = (t.nrows_padded / kChunkRows + 1 + 31) / 32 + 1;   // + 1: the kernel loads one word ahead
+    if (c->chunk_flag_words < flag_words) {
+        if (c->chunk_flags) (void)hipFree(c->chunk_flags);
+        c->chunk_flags = nullptr; c->chunk_flag_words = 0;
+        HIP_TRY(c->err, hipMalloc(&c->chunk_flags, (size_t)flag_words * sizeof(uint32_t)));
+        c->chunk_flag_words = flag_words;
+    }
     uint64_t col_begin, col_end;
     shard_columns(nsymbols, shard_index, shard_count, &col_begin, &col_end);
     uint32_t tb, te;
@@ -209,6 +218,10 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     HIP_TRY(c->err, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(ssv_pad_model, dim3((model_words + 255) / 256), dim3(256), 0, stream,
                        d_phmm, nrows, c->rows8, model_words);
+    // separator pairs score -128 twice in a row whatever the model says: with a mask every chunk tests every two steps
+    if (!c->pair_mask)
+        hipLaunchKernelGGL(ssv_chunk_flags, dim3((flag_words + 63) / 64), dim3(64), 0, stream,
+                           (const uint32_t*)c->rows8, t.nrows_padded, c->chunk_flags, flag_words);
     // sort key = segment | row | column in segment, each field only as wide as this problem needs
     unsigned row_bits = 1, seg_bits = 1;
     while ((1u << row_bits) < t.nrows_padded + 2u) row_bits++;
@@ -221,7 +234,8 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         hipLaunchKernelGGL(ssv_diag_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream,
                            d_sequence, (int64_t)nsymbols, (const uint32_t*)c->rows8, t.nrows_padded, t.first_diag,
                            tb, te, (int64_t)col_begin, (int64_t)col_end, d_hits, c->d_count,
-                           hit_capacity, d_abort_flag, c->pair_mask, row_bits);
+                           hit_capacity, d_abort_flag, c->pair_mask, row_bits,
+                           c->pair_mask ? (const uint32_t*)nullptr : (const uint32_t*)c->chunk_flags);
     }
     HIP_TRY(c->err, hipEventRecord(c->ev[2], stream));
     HIP_TRY(c->err, hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));

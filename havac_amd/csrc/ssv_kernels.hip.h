@@ -18,9 +18,11 @@
 //    score 0, and saturation at +32767 IS the threshold: score + match >= 256
 //    exactly when the sum leaves the int16 range.  Every regular value is a
 //    multiple of 256, so a crossed cell is recognisable afterwards by a non-zero
-//    low byte (0x7fff), and it stays recognisable for at least one more step
-//    (0x7fff + 256*m keeps the low byte unless it saturates again at the top).
-//    That is why hits are looked for only once per PAIR of steps.
+//    low byte (0x7fff), and it stays recognisable until it saturates at the
+//    bottom, i.e. until the scores added after the crossing sum to -256 or less.
+//    That is why hits are looked for only once per FOUR steps wherever three
+//    consecutive model rows cannot sum below -255 (ssv_chunk_flags marks those
+//    32-row chunks; elsewhere, and with separator masks, every two steps).
 //  * SKEWED PAIRS.  The two cells of a register sit on adjacent diagonals, and
 //    the high cell runs ONE ROW BEHIND the low cell: at step t the low cell is
 //    (row t, diagonal e) and the high cell (row t-1, diagonal e+1) -- the same
@@ -31,26 +33,29 @@
 //    per step pair, indexed by the 4-bit code of the symbol pair, returns both
 //    steps' match words in one conflict-free ds_read_b64 (16 entries x 2 banks
 //    = 32 distinct banks).  The wave rebuilds its 16 tables (2.2 KB) once per
-//    32-step chunk with 5 v_perm_b32 per lane.  A 17th entry per table scores
-//    -128 for "outside the matrix" (columns < 0 or >= N), which pins a cell at
-//    0 and can never hit: the hot loop has no per-cell predicate and no separate
-//    edge path.  The same entry serves the optional separator mask (boundary
-//    mode): a masked symbol pair takes 256 off every diagonal that crosses it,
-//    i.e. resets it.  What remains on the VALU per register and step pair is two
-//    v_pk_add_i16 and half a v_or3_b32.
-//  * The symbol window slides one position per step; the 32 step-pair codes a
-//    lane needs per chunk are addresses (code*8 + table base) held in VGPRs and
-//    indexed statically in the fully unrolled chunk, so the slide is free.
-//  * HITS are rare (about 1e-5 per cell on Dfam-like models): after each step
-//    pair the 16 score registers are OR-ed and one wave-wide test looks at the
-//    low bytes; only then the slow path runs, one marked lane at a time and on
-//    the SCALAR unit (v_readlane of the lane's registers, everything else SALU):
-//    it sorts out which step crossed, puts the crossed cells back to score 0
-//    (0x7fff + 1 = 0x8000; test/softSsv/SoftSsv.cpp:43-44) -- taking the second
-//    step again for cells that crossed on the first -- and writes the records
-//    into an LDS stage.  Records leave with one returning atomic per burst of
-//    128 and one per block at the end of the tile, and are put in the FPGA's
-//    order afterwards.
+//    32-step chunk with 5 v_perm_b32 per lane.  A 17th entry per table is for
+//    "outside the matrix" (columns < 0 or >= N): it scores 0, so a cell there
+//    keeps what it has and can never hit, and the hot loop has no per-cell
+//    predicate and no separate edge path.  With a separator mask (boundary
+//    mode) the same entry scores -128: a masked symbol pair takes 256 off every
+//    diagonal that crosses it, i.e. resets it.  What remains on the VALU per
+//    register and four steps is four v_pk_add_i16 and half a v_or3_b32.
+//  * The symbol window slides one position per step; the table addresses a lane
+//    needs (code*8 + table base, one per symbol pair) are held in VGPRs and
+//    indexed statically in the fully unrolled chunk, so the slide is free.  A
+//    window of four steps uses 17 consecutive addresses; the upper half of the
+//    chunk's 32 is expanded two entries per window (one SDWA v_or each), so
+//    only ~19 are alive at a time.
+//  * HITS are rare (about 1e-5 per cell on Dfam-like models): after each window
+//    the 16 score registers are OR-ed and one wave-wide test looks at the low
+//    bytes; only then the slow path runs, one marked lane and register at a
+//    time and on the SCALAR unit: the register's four steps are taken again
+//    from the scores the window started with (kept in the other register set),
+//    crossings are reported and put back to score 0 on the way (0x7fff + 1 =
+//    0x8000; test/softSsv/SoftSsv.cpp:43-44), and the exact result is written
+//    over the lane's register.  Records go to an LDS stage and leave with one
+//    returning atomic per burst of 128 and one per block at the end of the
+//    tile; they are put in the FPGA's order afterwards.
 //
 // Roofline: integer VALU issue; HBM
 // traffic is N/4 + 4*rows + 8*hits bytes per launch, thousands of cells per byte.
@@ -70,8 +75,10 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kModelSlack = 40;                   // padding rows kept behind the padded model (table look-ahead)
 constexpr uint32_t kScoreZero = 0x80008000u;      // two cells at score 0: 256*0 - 32768
 constexpr uint32_t kCrossedBits = 0x00010001u;    // bit 0 of either cell: set only in 0x7fff-derived values
-constexpr uint32_t kOutsideWord = 0x80008000u;    // match word "score -128" for both cells
-constexpr uint32_t kPadRow = 0x80808080u;         // a row outside the model: -128 for every symbol
+constexpr uint32_t kOutsideReset = 0x80008000u;   // match word "score -128" for both cells (separator pairs: two of them reset a diagonal)
+constexpr uint32_t kOutsideNeutral = 0u;          // match word "score 0": columns outside the matrix when there are no separators
+constexpr uint32_t kPadRow = 0u;                  // a row outside the model scores 0 for every symbol: it changes nothing and can never hit
+constexpr int kWindowSteps = 4;                   // steps between two hit tests where the model allows it (ssv_chunk_flags)
 
 // per-wave LDS: 16 step-pair tables of 17 entries x 8 B, the record stage
 constexpr int kPairStride = 17 * 8;               // 16 symbol-pair codes + the "outside the matrix" entry
@@ -105,13 +112,43 @@ __device__ __forceinline__ uint64_t record_to_key(uint64_t rec, uint32_t row_bit
 
 // ---------------------------------------------------------------------------
 // model int8 [row][A,C,G,T] -> the same words shifted by one: out[0] is "row -1"
-// (all -128), out[1 + r] is row r, and everything from row nrows on is -128
-// again (a padding row can only lower a score).  nrows_padded + kModelSlack words.
+// (all 0), out[1 + r] is row r, and everything from row nrows on is 0 again (a
+// padding row leaves every score as it is and can never hit; it must not LOWER a
+// score either, or a crossing on the model's last rows could lose its mark before
+// the next hit test, see step_window).  nrows_padded + kModelSlack words.
 __global__ void ssv_pad_model(const int8_t* __restrict__ phmm, uint32_t nrows,
                               uint32_t* __restrict__ rows, uint32_t nwords) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nwords) return;
     rows[i] = (i >= 1 && i <= nrows) ? reinterpret_cast<const uint32_t*>(phmm)[i - 1] : kPadRow;
+}
+
+// Which 32-step chunks may test for hits every FOUR steps instead of every two.  A crossed cell is recognised by its
+// low byte (0x7fff), and it loses that mark only by saturating at the bottom, i.e. when the scores added after the
+// crossing sum to -256 or less.  Inside a window of four steps at most three steps follow a crossing, so a chunk is
+// safe when no three consecutive rows it touches (rows 32c-1 .. 32c+31: the high cells run one row behind) can sum
+// below -255 whatever the symbols are.  One bit per chunk; `rows` is the padded model of ssv_pad_model.
+__global__ void ssv_chunk_flags(const uint32_t* __restrict__ rows, uint32_t nrows_padded, uint32_t* __restrict__ flags,
+                                uint32_t nwords) {
+    const uint32_t word = blockIdx.x * blockDim.x + threadIdx.x;
+    if (word >= nwords) return;
+    auto lowest = [&](uint32_t index) -> int {          // min(0, the four scores of rows[index]); 0 beyond the array
+        if (index >= nrows_padded + kModelSlack) return 0;
+        const uint32_t r = rows[index];
+        int m = 0;
+        for (int a = 0; a < 4; a++) m = min(m, (int)(int8_t)(r >> (8 * a)));
+        return m;
+    };
+    uint32_t bits = 0;
+    for (uint32_t b = 0; b < 32; b++) {
+        const uint32_t p0 = (word * 32 + b) * kChunkRows;
+        if (p0 >= nrows_padded + kChunkRows) break;
+        bool safe = true;
+        // rows p0-1 .. p0+31 are rows[p0 .. p0+32]: every run of three of them
+        for (uint32_t t = p0; t <= p0 + kChunkRows - 2 && safe; t++) safe = lowest(t) + lowest(t + 1) + lowest(t + 2) >= -255;
+        bits |= (safe ? 1u : 0u) << b;
+    }
+    flags[word] = bits;
 }
 
 // ---------------------------------------------------------------------------
@@ -165,19 +202,6 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) u32x2* lds_words_t;
 typedef __attribute__((address_space(3))) u32x2* lds_words_out_t;
 
-__device__ __forceinline__ uint32_t sat_add_pk16(uint32_t a, uint32_t b) {
-    short2v r = __builtin_elementwise_add_sat(__builtin_bit_cast(short2v, a),
-                                              __builtin_bit_cast(short2v, b));
-    return __builtin_bit_cast(uint32_t, r);
-}
-
-// 8 bytes = 32 symbols at symbol offset `pos` (multiple of 32); zero outside the buffer
-__device__ __forceinline__ uint2 load_symbols(const uint8_t* __restrict__ seq, int64_t nsymbols, int64_t pos,
-                                              bool checked) {
-    if (checked && (pos < 0 || pos + 32 > nsymbols)) return make_uint2(0u, 0u);
-    return *reinterpret_cast<const uint2*>(seq + (pos >> 2));
-}
-
 // ---- per-wave LDS ------------------------------------------------------------
 struct __attribute__((aligned(128))) WaveLds {
     uint8_t table[kTableBytes];            // match words of the current chunk
@@ -186,12 +210,11 @@ struct __attribute__((aligned(128))) WaveLds {
 
 // ---- hit queue --------------------------------------------------------------
 // Counterpart of the FPGA's five-stage hit sieve (device/HitReporting.cpp:12-417).
-// A wave that sees a crossing turns it into a record at once (step_pair's slow
-// path, on the scalar unit) and stages it in LDS; staged records are
-// appended to the global queue in bursts: one returning atomic per burst
-// instead of one per hit (a single counter word sustains only ~90 returning
-// atomics per microsecond chip-wide, which capped the first version of this
-// kernel at ~90 M hits/s).
+// A wave that sees a crossing turns it into a record at once (window_slow, on the
+// scalar unit) and stages it in LDS; staged records are appended to the global
+// queue in bursts: one returning atomic per burst instead of one per hit (a single
+// counter word sustains only ~90 returning atomics per microsecond chip-wide, which
+// capped the first version of this kernel at ~90 M hits/s).
 struct HitSink {
     uint64_t* hits;                // global queue of sort keys (hit_key)
     unsigned long long* hit_count; // records found so far (may run past capacity)
@@ -201,14 +224,9 @@ struct HitSink {
     uint32_t row_bits;             // width of the row field of the sort key
 };
 
-__device__ __forceinline__ int64_t uniform_i64(int64_t v) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
-    return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-
-__device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t staged, int lane) {
+__device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t staged) {
     if (staged == 0) return 0;
+    const uint32_t lane = __lane_id();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(sink.hit_count, (unsigned long long)staged);
@@ -224,8 +242,8 @@ __device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t sta
 }
 
 // A full stage leaves with one returning atomic (a real call: rare, and its registers stay out of the hot loop).
-__device__ __noinline__ uint32_t flush_full(const HitSink sink, uint32_t staged, int lane) {
-    return flush_hits(sink, __builtin_amdgcn_readfirstlane(staged), lane);
+__device__ __noinline__ uint32_t flush_full(const HitSink sink, uint32_t staged) {
+    return flush_hits(sink, __builtin_amdgcn_readfirstlane(staged));
 }
 
 // Two int16 saturating adds on the scalar unit (the slow path's copy of v_pk_add_i16 ... clamp).
@@ -237,23 +255,14 @@ __device__ __forceinline__ uint32_t scalar_sat_add_pk16(uint32_t a, uint32_t b) 
     return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
 }
 
-// Records of one lane's crossings at step t.  Bit i of `marks` = the low cell of register i, bit 16 + i = its high
-// cell.  At step t the low cell of register i of lane l is (row t, column c) and the high cell (row t - 1, column c),
-// with c = wave_diag0 + 32*l + 2*i + t.  Everything here is wave-uniform: it runs on the scalar unit, which this
-// VALU-bound kernel leaves idle; per record the VALU only moves the key to the LDS stage.
-__device__ __forceinline__ uint32_t emit_marks(const HitSink& sink, uint32_t staged, uint32_t marks, uint32_t t,
-                                               uint32_t l, int64_t wave_diag0, int lane) {
-    const auto lds = (__attribute__((address_space(3))) WaveLds*)sink.lds;
-    while (marks) {
-        const uint32_t q = (uint32_t)__builtin_ctz(marks);
-        marks &= marks - 1;
-        const uint32_t reg = q & 15, high = q >> 4;
-        const int64_t column = wave_diag0 + (int64_t)(32 * l + 2 * reg + t);
-        if (column < sink.col_begin || column >= sink.col_end) continue;   // halo columns belong to the neighbouring shard
-        const uint64_t key = hit_key(t - high, (uint64_t)column, sink.row_bits);
-        if (lane == 0) lds->stage[staged] = key;
+// One record of the slow path: cell (row, column), wave-uniform.
+__device__ __forceinline__ uint32_t emit_cell(const HitSink& sink, uint32_t staged, uint32_t row, int64_t column) {
+    if (column >= sink.col_begin && column < sink.col_end) {      // halo columns belong to the neighbouring shard
+        const auto lds = (__attribute__((address_space(3))) WaveLds*)sink.lds;
+        const uint64_t key = hit_key(row, (uint64_t)column, sink.row_bits);
+        if (__lane_id() == 0) lds->stage[staged] = key;
         staged++;
-        if (staged == kHitStage) staged = flush_full(sink, staged, lane);
+        if (staged == kHitStage) staged = flush_full(sink, staged);
     }
     return staged;
 }
@@ -264,92 +273,243 @@ __device__ __forceinline__ u32x2 match_words(uint32_t code_addr) {
     return *(lds_words_t)(uintptr_t)(code_addr + P * kPairStride);
 }
 
-// Steps 2P and 2P+1 of the chunk over the lane's 32 diagonals.  P is a template parameter so that
-// every window index and LDS offset is a compile-time constant.
-//
-// The scores ping-pong between two register sets: on entry `cur` holds the scores, the first step
-// updates `cur` in place (it then holds the scores after step 2P, which the slow path needs), the
-// second step writes `nxt`; the next pair is instantiated with the sets swapped.  The first add is
-// written as read-modify-write asm, which pins a score to its VGPR through the unrolled chunk (left
-// to itself hipcc re-homes the 16 registers with v_mov after every pair; measured on C2: both adds
-// plain 2.62 ms, both asm 2.49 ms, first asm + second plain 2.39 ms).
-template <int P>
-__device__ __forceinline__ void step_pair(uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
-                                          const HitSink& sink, uint32_t& staged, uint32_t step0, int64_t wave_diag0,
-                                          int lane) {
-    uint32_t any = 0;
-    u32x2 m[kRegs];
-#pragma unroll
-    for (int i = 0; i < kRegs; i++) m[i] = match_words<P>(C[P + i]);
-    __builtin_amdgcn_sched_barrier(0);      // all 16 reads in flight before the first add waits (hipcc otherwise staggers them)
-#pragma unroll
-    for (int i = 0; i < kRegs; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(cur[i]) : "v"(m[i].x));
-#pragma unroll
-    for (int i = 0; i < kRegs; i++) {
-        nxt[i] = sat_add_pk16(cur[i], m[i].y);
-        any |= nxt[i];
+// ---- the symbol window, expanded as the windows reach it --------------------------------------------------------
+// A chunk of 32 steps looks at 64 symbols per lane = 32 symbol pairs; C[k] is the LDS address of the table entry of
+// pair k (code * 8 | table base).  Pairs 0..15 are the upper half of the previous chunk's window; pairs 16..31 come from
+// the 8 bytes loaded for this chunk and are expanded entry by entry: window Q (steps 4Q..4Q+3) uses entries 2Q..2Q+16
+// only, so 17 of the 32 addresses (plus the four prepared words) are alive at a time -- the registers that let both
+// score sets stay alive at five waves per SIMD.
+struct LazySymbols {
+    uint32_t even[2], odd[2];   // per packed word (pairs 16..23, 24..31): code*8 of its even / odd pairs, one per byte
+    uint32_t separators;        // bit K: pair 16+K is a separator pair (boundary mode); 0 otherwise
+    uint32_t table_base;
+    bool special;               // wave-uniform: some position of the wave lies outside [0, N), or a separator is present
+    uint32_t lane8;             // 8 * lane; 32 * lane is the lane's first position relative to the wave's (only read when special)
+    int32_t valid_lo, valid_hi; // wave-uniform: positions relative to the wave's first that lie inside [0, N): [valid_lo, valid_hi)
+};
+
+__device__ __forceinline__ void prepare_symbols(LazySymbols& z, uint32_t lo, uint32_t hi) {
+    // pair n of a word = its bits [4n+3:4n]; code*8 = bits [6:3] of a byte: even pairs (w << 3), odd pairs (w >> 1)
+    z.even[0] = (lo << 3) & 0x78787878u; z.odd[0] = (lo >> 1) & 0x78787878u;
+    z.even[1] = (hi << 3) & 0x78787878u; z.odd[1] = (hi >> 1) & 0x78787878u;
+}
+
+template <int BYTE>
+__device__ __forceinline__ uint32_t or_byte(uint32_t base, uint32_t word) {   // base | ((word >> 8*BYTE) & 0xff), one SDWA instruction
+    uint32_t out;
+    if constexpr (BYTE == 0) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(out) : "s"(base), "v"(word));
+    if constexpr (BYTE == 1) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(out) : "s"(base), "v"(word));
+    if constexpr (BYTE == 2) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(out) : "s"(base), "v"(word));
+    if constexpr (BYTE == 3) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(out) : "s"(base), "v"(word));
+    return out;
+}
+
+template <int K>
+__device__ __forceinline__ void expand_entry(uint32_t (&C)[32], const LazySymbols& z) {
+    constexpr int n = K & 7;
+    uint32_t entry = or_byte<n / 2>(z.table_base, (n & 1) ? z.odd[K / 8] : z.even[K / 8]);
+    if (z.special) {
+        // positions outside [0, N) and separator pairs use the 17th entry of the tables
+        uint32_t lane32 = z.lane8 * 4;
+        asm volatile("" : "+v"(lane32));                        // computed here, in the rare chunks that need it: hipcc otherwise
+                                                                // hoists the 16 sums below out of the chunk loop and spills them
+        const int32_t q = (int32_t)lane32 + 2 * K;              // the pair's positions q and q+1 are in or out together
+        if (q < z.valid_lo || q >= z.valid_hi || ((z.separators >> K) & 1u)) entry = z.table_base + kOutsideCode;
     }
-    if (__builtin_expect(__any((any & kCrossedBits) != 0), 0)) {
-        // (the lane mask is taken again inside: the hot test stays v_cmp -> vcc -> s_cbranch_vccnz)
-        unsigned long long lanes = __ballot((any & kCrossedBits) != 0);
-        // Slow path, one lane at a time on the scalar unit (typically one lane, one register).  A crossed cell holds
-        // exactly 0x7fff; "restart from 0" (SoftSsv.cpp:43-44) is + 1 on that int16 (0x8000 = score 0).  A cell that
-        // crossed on the first step still shows its mark on `nxt`; it gets the + 1 on `cur` and takes the second step again.
-        do {
-            const uint32_t l = (uint32_t)__builtin_ctzll(lanes);
-            lanes &= lanes - 1;
-            const bool mine = (uint32_t)lane == l;
-            uint32_t first = 0, second = 0;     // bit i: low cell of register i, bit 16 + i: its high cell
-#pragma unroll
-            for (int i = 0; i < kRegs; i++) {
-                uint32_t n = __builtin_amdgcn_readlane(nxt[i], l);
-                if (n & kCrossedBits) {
-                    uint32_t c = __builtin_amdgcn_readlane(cur[i], l);
-                    const uint32_t f = c & kCrossedBits;
-                    if (f) {
-                        c += f;
-                        n = scalar_sat_add_pk16(c, __builtin_amdgcn_readlane(match_words<P>(C[P + i]).y, l));
-                        first |= f << i;
-                    }
-                    const uint32_t sec = n & kCrossedBits;
-                    n += sec;
-                    second |= sec << i;
-                    nxt[i] = mine ? n : nxt[i];
-                }
-            }
-            staged = emit_marks(sink, staged, first, step0 + 2 * P, l, wave_diag0, lane);
-            staged = emit_marks(sink, staged, second, step0 + 2 * P + 1, l, wave_diag0, lane);
-        } while (lanes);
+    C[16 + K] = entry;
+}
+
+// what window Q needs beyond what window Q-1 had: entries 2Q+15 and 2Q+16 (window 0: entry 16)
+template <int Q>
+__device__ __forceinline__ void expand_for_window(uint32_t (&C)[32], const LazySymbols& z) {
+    if constexpr (Q == 0) {
+        expand_entry<0>(C, z);
+    } else {
+        expand_entry<2 * Q - 1>(C, z);
+        expand_entry<2 * Q>(C, z);
     }
 }
 
-// pairs First .. First+N-1; the scores are in `a` on entry and, N being even, in `a` again on exit
-template <int First, int... I>
-__device__ __forceinline__ void step_pairs(uint32_t (&a)[kRegs], uint32_t (&b)[kRegs], const uint32_t (&C)[32],
-                                           const HitSink& sink, uint32_t& staged, uint32_t step0, int64_t wave_diag0,
-                                           int lane, std::integer_sequence<int, I...>) {
-    static_assert(sizeof...(I) % 2 == 0, "an even number of pairs returns the scores to the first set");
-    ((I % 2 == 0 ? step_pair<First + I>(a, b, C, sink, staged, step0, wave_diag0, lane)
-                 : step_pair<First + I>(b, a, C, sink, staged, step0, wave_diag0, lane)), ...);
+template <int... K>
+__device__ __forceinline__ void expand_all(uint32_t (&C)[32], const LazySymbols& z, std::integer_sequence<int, K...>) {
+    (expand_entry<K>(C, z), ...);
+}
+
+// ---- the slow path ------------------------------------------------------------------------------------------------
+// What the slow path of a window needs of register I of lane l: the scores the window started from and the LDS
+// addresses of the two table entries its four match words came from.  Selected by a chain of scalar compares on the
+// register number, so that the replay exists once per window and not once per register.  Written as asm: left as
+// plain C++, hipcc folds the chain into ONE dynamically indexed access, for which the 16 score registers (and the 32
+// window registers) have to live in consecutive VGPRs -- it then spills them as whole tuples inside the hot loop.
+template <int Q, int I>
+__device__ __forceinline__ void window_inputs(uint32_t l, const uint32_t (&cur)[kRegs], const uint32_t (&C)[32],
+                                              uint32_t& s, uint32_t& entry0, uint32_t& entry1) {
+    asm volatile("v_readlane_b32 %0, %3, %6\n\tv_readlane_b32 %1, %4, %6\n\tv_readlane_b32 %2, %5, %6"
+                 : "=&s"(s), "=&s"(entry0), "=&s"(entry1)
+                 : "v"(cur[I]), "v"(C[2 * Q + I]), "v"(C[2 * Q + 1 + I]), "s"(l));
+}
+
+// Lane l of score register r (0..15, wave-uniform) := s.  ONE asm statement that names all 16 registers and branches
+// inside: written as sixteen conditional C++ statements, the merge of the sixteen paths makes hipcc treat the register
+// set as one 512-bit value that it copies and spills as a whole in the hot loop (1.2 KB of scratch).
+__device__ __forceinline__ void write_score_lane(uint32_t (&n)[kRegs], uint32_t s, uint32_t l, uint32_t r) {
+    static_assert(kRegs == 16, "the asm below names sixteen registers");
+    asm volatile("s_mov_b32 m0, %[l]\n\t"
+                 "s_cmp_eq_u32 %[r], 0\n\ts_cbranch_scc1 .Lhavac_w0_%=\n\t"
+                 "s_cmp_eq_u32 %[r], 1\n\ts_cbranch_scc1 .Lhavac_w1_%=\n\t"
+                 "s_cmp_eq_u32 %[r], 2\n\ts_cbranch_scc1 .Lhavac_w2_%=\n\t"
+                 "s_cmp_eq_u32 %[r], 3\n\ts_cbranch_scc1 .Lhavac_w3_%=\n\t"
+                 "s_cmp_eq_u32 %[r], 4\n\ts_cbranch_scc1 .Lhavac_w4_%=\n\t"
+                 "s_cmp_eq_u32 %[r], 5\n\ts_cbranch_scc1 .Lhavac_w5_%=\n\t"
+                 "s_cmp_eq_u32 %[r], 6\n\ts_cbranch_scc1 .Lhavac_w6_%=\n\t"
+                 "s_cmp_eq_u32 %[r], 7\n\ts_cbranch_scc1 .Lhavac_w7_%=\n\t"
+                 "s_cmp_eq_u32 %[r], 8\n\ts_cbranch_scc1 .Lhavac_w8_%=\n\t"
+                 "s_cmp_eq_u32 %[r], 9\n\ts_cbranch_scc1 .Lhavac_w9_%=\n\t"
+                 "s_cmp_eq_u32 %[r], 10\n\ts_cbranch_scc1 .Lhavac_w10_%=\n\t"
+                 "s_cmp_eq_u32 %[r], 11\n\ts_cbranch_scc1 .Lhavac_w11_%=\n\t"
+                 "s_cmp_eq_u32 %[r], 12\n\ts_cbranch_scc1 .Lhavac_w12_%=\n\t"
+                 "s_cmp_eq_u32 %[r], 13\n\ts_cbranch_scc1 .Lhavac_w13_%=\n\t"
+                 "s_cmp_eq_u32 %[r], 14\n\ts_cbranch_scc1 .Lhavac_w14_%=\n\t"
+                 "v_writelane_b32 %15, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w0_%=:\n\tv_writelane_b32 %0, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w1_%=:\n\tv_writelane_b32 %1, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w2_%=:\n\tv_writelane_b32 %2, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w3_%=:\n\tv_writelane_b32 %3, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w4_%=:\n\tv_writelane_b32 %4, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w5_%=:\n\tv_writelane_b32 %5, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w6_%=:\n\tv_writelane_b32 %6, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w7_%=:\n\tv_writelane_b32 %7, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w8_%=:\n\tv_writelane_b32 %8, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w9_%=:\n\tv_writelane_b32 %9, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w10_%=:\n\tv_writelane_b32 %10, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w11_%=:\n\tv_writelane_b32 %11, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w12_%=:\n\tv_writelane_b32 %12, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w13_%=:\n\tv_writelane_b32 %13, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w14_%=:\n\tv_writelane_b32 %14, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_wend_%=:"
+                 : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]), "+v"(n[6]), "+v"(n[7]),
+                   "+v"(n[8]), "+v"(n[9]), "+v"(n[10]), "+v"(n[11]), "+v"(n[12]), "+v"(n[13]), "+v"(n[14]), "+v"(n[15])
+                 : [s] "s"(s), [l] "s"(l), [r] "s"(r)
+                 : "m0", "scc");
+}
+
+// `marked` (per lane) = OR of the score registers after NSTEPS (2 or 4) steps of window Q.  For every lane and register
+// that shows a mark: take the register's NSTEPS steps again on the scalar unit from `cur` (the scores the window started
+// from), report the crossings of steps >= report_from (an unsafe window has reported those of its first two steps at
+// its middle already), restart crossed cells from score 0 on the way, and write the exact result over `nxt`.
+// At step t the low cell of register r of lane l is (row t, column c) and the high cell (row t - 1, column c),
+// c = wave_diag0 + 32 l + 2 r + t.
+template <int Q, int NSTEPS, int... I>
+__device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
+                                            uint32_t marked, int report_from, const HitSink& sink, uint32_t& staged,
+                                            uint32_t step0, int64_t wave_diag0, std::integer_sequence<int, I...>) {
+    unsigned long long lanes = __ballot((marked & kCrossedBits) != 0);
+    do {
+        const uint32_t l = (uint32_t)__builtin_ctzll(lanes);
+        lanes &= lanes - 1;
+        uint32_t regs = 0;                 // the lane's marked registers
+        ((regs |= (__builtin_amdgcn_readlane(nxt[I], l) & kCrossedBits) ? (1u << I) : 0u), ...);
+        do {
+            const uint32_t r = (uint32_t)__builtin_ctz(regs);
+            regs &= regs - 1;
+            uint32_t s = 0, entry0 = 0, entry1 = 0;
+            ((r == (uint32_t)I ? window_inputs<Q, I>(l, cur, C, s, entry0, entry1) : (void)0), ...);
+            // the match words again, from the lane's table entries (uniform addresses: every lane reads the same)
+            uint32_t w[kWindowSteps] = {0, 0, 0, 0};
+            const u32x2 wa = match_words<2 * Q>(entry0);
+            w[0] = (uint32_t)__builtin_amdgcn_readfirstlane(wa.x);
+            w[1] = (uint32_t)__builtin_amdgcn_readfirstlane(wa.y);
+            if constexpr (NSTEPS > 2) {
+                const u32x2 wb = match_words<2 * Q + 1>(entry1);
+                w[2] = (uint32_t)__builtin_amdgcn_readfirstlane(wb.x);
+                w[3] = (uint32_t)__builtin_amdgcn_readfirstlane(wb.y);
+            }
+            const uint32_t t0 = step0 + kWindowSteps * Q;
+            const int64_t column0 = wave_diag0 + (int64_t)(32 * l + 2 * r) + (int64_t)t0;
+#pragma unroll
+            for (int k = 0; k < NSTEPS; k++) {
+                s = scalar_sat_add_pk16(s, w[k]);
+                const uint32_t f = s & kCrossedBits;
+                if (f) {
+                    if (k >= report_from) {
+                        if (f & 1u) staged = emit_cell(sink, staged, t0 + k, column0 + k);
+                        if (f >> 16) staged = emit_cell(sink, staged, t0 + k - 1, column0 + k);
+                    }
+                    s += f;
+                }
+            }
+            write_score_lane(nxt, s, l, r);
+        } while (regs);
+    } while (lanes);
+}
+
+// Steps 4Q .. 4Q+3 of the chunk.  `cur` is left untouched (the first add is not in place) and holds the scores the window
+// started from; `nxt` receives the scores after the four steps; the next window swaps the two sets.  One hit test at
+// the end where ssv_chunk_flags says that is exact (`safe`, wave-uniform), else one more in the middle.
+template <int Q, int... I>
+__device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
+                                            bool safe, const HitSink& sink, uint32_t& staged, uint32_t step0,
+                                            int64_t wave_diag0, std::integer_sequence<int, I...> regs) {
+    static_assert(sizeof...(I) == kRegs, "one index per score register");
+    u32x2 m[kRegs];
+    __builtin_amdgcn_sched_barrier(0);      // no reads of this window above the previous window's last adds: no registers for them
+#pragma unroll
+    for (int i = 0; i < kRegs; i++) m[i] = match_words<2 * Q>(C[2 * Q + i]);
+    __builtin_amdgcn_sched_barrier(0);      // all 16 reads in flight before the first add waits (hipcc otherwise staggers them)
+#pragma unroll
+    for (int i = 0; i < kRegs; i++) asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(nxt[i]) : "v"(cur[i]), "v"(m[i].x));
+#pragma unroll
+    for (int i = 0; i < kRegs; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[i]) : "v"(m[i].y));
+    if (!safe) {
+        uint32_t any = 0;
+#pragma unroll
+        for (int i = 0; i < kRegs; i++) any |= nxt[i];
+        if (__builtin_expect(__any((any & kCrossedBits) != 0), 0))
+            window_slow<Q, 2>(cur, nxt, C, any, 0, sink, staged, step0, wave_diag0, regs);
+    }
+    __builtin_amdgcn_sched_barrier(0);      // the second reads stay behind the adds above (their registers are the first reads')
+#pragma unroll
+    for (int i = 0; i < kRegs; i++) m[i] = match_words<2 * Q + 1>(C[2 * Q + 1 + i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < kRegs; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[i]) : "v"(m[i].x));
+#pragma unroll
+    for (int i = 0; i < kRegs; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[i]) : "v"(m[i].y));
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < kRegs; i++) any |= nxt[i];
+    if (__builtin_expect(__any((any & kCrossedBits) != 0), 0))
+        window_slow<Q, kWindowSteps>(cur, nxt, C, any, safe ? 0 : 2, sink, staged, step0, wave_diag0, regs);
+}
+
+// windows 0 .. N-1 of a chunk; the scores are in `a` on entry and, N being even, in `a` again on exit
+template <int... Q>
+__device__ __forceinline__ void step_windows(uint32_t (&a)[kRegs], uint32_t (&b)[kRegs], uint32_t (&C)[32],
+                                             const LazySymbols& z, bool safe, const HitSink& sink, uint32_t& staged,
+                                             uint32_t step0, int64_t wave_diag0, std::integer_sequence<int, Q...>) {
+    static_assert(sizeof...(Q) % 2 == 0 && sizeof...(Q) * kWindowSteps == kChunkRows, "a whole chunk, an even number of windows");
+    ((expand_for_window<Q>(C, z),
+      (Q % 2 == 0 ? step_window<Q>(a, b, C, safe, sink, staged, step0, wave_diag0, std::make_integer_sequence<int, kRegs>{})
+                  : step_window<Q>(b, a, C, safe, sink, staged, step0, wave_diag0, std::make_integer_sequence<int, kRegs>{}))), ...);
+    expand_entry<15>(C, z);      // entry 31: entry 15 of the next chunk
 }
 
 // selector of the match word of symbol a: bytes [0x0c, a, 0x0c, 4 + a]; with v_perm(S0 = row t-1, S1 = row t) it
 // yields (row_t[a] << 8) | (row_tm1[a] << 24)
 __device__ __forceinline__ uint32_t word_selector(uint32_t a) { return 0x040c000cu + a * 0x01000100u; }
 
-// 5 waves per SIMD: 96 VGPRs, no scratch.  Measured on C2 with the scalar slow path: 4 waves (106 VGPRs) 2.21 ms,
-// 5 waves 2.12 ms; without hits 2.02 / 1.98 ms.  (With the earlier vector slow path the kernel needed 121 VGPRs and
-// 5 waves spilled badly; 3 waves are 7 % slower.)
+// 5 waves per SIMD: 96 VGPRs.  cur 16 + nxt 16 + 32 match words in flight + ~19 window addresses + 4 prepared symbol words.
 __global__ __launch_bounds__(64 * kWavesPerBlock, 5)
 void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, const uint32_t* __restrict__ rows,
                      const uint32_t nrows_padded, const int64_t first_diag, const uint32_t tile_begin,
                      const uint32_t tile_end, const int64_t col_begin, const int64_t col_end,
                      uint64_t* __restrict__ hits, unsigned long long* __restrict__ hit_count,
                      const uint64_t hit_capacity, const uint32_t* __restrict__ abort_flag,
-                     const uint16_t* __restrict__ pair_mask, const uint32_t row_bits) {
+                     const uint16_t* __restrict__ pair_mask, const uint32_t row_bits,
+                     const uint32_t* __restrict__ safe_chunks) {
     __shared__ WaveLds wave_lds[kWavesPerBlock];
 
-    const int lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63;
     // readfirstlane: everything derived from the tile index is wave-uniform (SALU branches, scalar address math)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds* const lds = &wave_lds[wave];
@@ -357,17 +517,25 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
     uint32_t staged = 0;          // wave-uniform
 
     // LDS byte address of this wave's tables (a multiple of 128: code*8 is OR-ed into it)
-    const uint32_t table_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds->table;
+    const uint32_t table_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds->table);
     // this lane's share of the table build: the four entries (a, b) with b = lane & 3 of step pair lane >> 2
     const uint32_t my_pair = lane >> 2, my_b = lane & 3;
-    const uint32_t sel_second = word_selector(my_b);
-    const uint32_t my_entries_addr = table_base + my_pair * kPairStride + my_b * 32;
-    if (my_b == 0)        // the "outside the matrix" entry of each table never changes
-        *(lds_words_out_t)(uintptr_t)(table_base + my_pair * kPairStride + kOutsideCode) = u32x2{kOutsideWord, kOutsideWord};
+    const uint32_t lane8 = lane * 8;            // byte offset of the lane's 32 symbols in the wave's 512 packed bytes
+    // What a lane needs once per chunk for the table build and the model-row fetch lives in LDS, not in three VGPRs
+    // that would be idle through the windows: {selector of its second match word, LDS offset of its four entries,
+    // byte offset of its step pair in a chunk's rows}.  Every wave writes the same values and reads back its own.
+    __shared__ uint4 lane_consts[64];
+    lane_consts[lane] = make_uint4(word_selector(my_b), my_pair * kPairStride + my_b * 32, my_pair * 8, 0u);
+    if (my_b == 0) {      // the "outside the matrix" entry of each table never changes
+        // Without separators it scores 0: a cell outside the matrix keeps what it has (0 before a diagonal enters at
+        // column 0; behind the last column nothing is reported any more) and a mark is never lost there.  With a
+        // separator mask the same entry scores -128: two of them reset every diagonal through a separator pair.
+        const uint32_t outside = pair_mask ? kOutsideReset : kOutsideNeutral;
+        *(lds_words_out_t)(uintptr_t)(table_base + my_pair * kPairStride + kOutsideCode) = u32x2{outside, outside};
+    }
 
     const uint32_t tile = tile_begin + blockIdx.x * kWavesPerBlock + wave;
     const int64_t d0 = first_diag + (int64_t)tile * kTileDiags;     // wave's first diagonal
-    const int64_t dl = d0 + lane * kDiagsPerLane;                   // lane's first diagonal
     // steps whose cells of this tile can lie inside the matrix
     int64_t p_lo = -d0 - kTileDiags;                                // first chunk touching column >= 0
     if (p_lo < 0) p_lo = 0;
@@ -375,93 +543,88 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
     if (p_hi > (int64_t)nrows_padded) p_hi = nrows_padded;
     // no early return: every wave of the block meets the others at the final flush
     if (tile < tile_end && p_lo < p_hi) {
-        uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_pair)
+        uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_window)
 #pragma unroll
         for (int i = 0; i < kRegs; i++) x[i] = x2[i] = kScoreZero;
 
-        // Window of the current chunk, symbol positions [j, j+64) with j = dl + p0: C[k] is the LDS address of the
-        // table entry of the symbol pair (j+2k, j+2k+1).  The upper half of one chunk's window is the lower half of the
-        // next, so each chunk expands only the 32 new symbols.
+        // Window of the current chunk, symbol positions [j, j+64) with j = d0 + 32 lane + p0 (see LazySymbols)
         uint32_t C[32];
-        // packed symbols [dl+rel, dl+rel+32) in x,y; in z the 16 separator bits of those symbol pairs (boundary mode);
-        // rel is wave-uniform
-        auto fetch_symbols = [&](int64_t rel) -> uint3 {
-            const bool edge = (d0 + rel < 0) || (d0 + rel + kTileDiags > nsymbols);   // the wave's 2048 positions
-            const int64_t pos = dl + rel;
-            const uint2 w = load_symbols(seq, nsymbols, pos, edge);
-            uint32_t separators = 0;
-            if (pair_mask && pos >= 0 && pos + 32 <= nsymbols) separators = pair_mask[pos >> 5];
-            return make_uint3(w.x, w.y, separators);
-        };
-        auto expand = [&](const uint3 packed, int64_t rel) {  // -> C[16 .. 32)
-            const bool edge = (d0 + rel < 0) || (d0 + rel + kTileDiags > nsymbols);
-            const int64_t pos = dl + rel;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t w = k < 8 ? packed.x : packed.y;
-                const int sh = (k & 7) * 4;                                  // the pair's 4 bits start here
-                const uint32_t code8 = sh == 0 ? (w << 3) : (w >> (sh - 3)); // code * 8 in bits [6:3]
-                C[16 + k] = (code8 & 0x78u) | table_base;
-            }
-            if (edge) {
-                // positions outside [0, N) use the entry that scores -1: pins the cell at 0, never hits
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const int64_t q = pos + 2 * k;     // q and q+1 are in or out together (pos, N even)
-                    if (q < 0 || q >= nsymbols) C[16 + k] = table_base + kOutsideCode;
-                }
-            }
-            if (pair_mask && __any(packed.z != 0)) {
-                // boundary mode: a separator pair scores -128 twice on every diagonal through it = a reset
-#pragma unroll
-                for (int k = 0; k < 16; k++)
-                    if ((packed.z >> k) & 1u) C[16 + k] = table_base + kOutsideCode;
-            }
+        // The 32 symbols (8 bytes) of this lane at position d0 + rel + 32 lane, rel wave-uniform, ready for expansion;
+        // the wave's 512 bytes are consecutive: a uniform base and the lane's byte offset.
+        auto fetch_symbols = [&](int64_t rel, LazySymbols& z) {
+            const int64_t first = d0 + rel;                               // the wave's first position
+            const bool edge = (first < 0) || (first + kTileDiags > nsymbols);
+            const uint8_t* const base = seq + (first >> 2);               // only dereferenced for lanes inside [0, N)
+            const int64_t lo = -first, hi = nsymbols - first;             // positions relative to `first` that are inside
+            z.valid_lo = __builtin_amdgcn_readfirstlane((int32_t)(lo < 0 ? 0 : (lo > 4096 ? 4096 : lo)));
+            z.valid_hi = __builtin_amdgcn_readfirstlane((int32_t)(hi < 0 ? 0 : (hi > 4096 ? 4096 : hi)));
+            z.lane8 = lane8;
+            z.table_base = table_base;
+            const bool inside = !edge || ((int32_t)(lane8 * 4) >= z.valid_lo && (int32_t)(lane8 * 4) + 32 <= z.valid_hi);
+            uint2 w = make_uint2(0u, 0u);
+            if (inside) w = *reinterpret_cast<const uint2*>(base + lane8);
+            z.separators = 0;
+            if (pair_mask && inside) z.separators = pair_mask[(first >> 5) + lane];
+            z.special = edge || (pair_mask && __any(z.separators != 0));
+            prepare_symbols(z, w.x, w.y);
         };
         // A chunk's 16 step-pair tables: entry (a,b) of pair P = { word(step 2P, a), word(step 2P+1, b) } with
         // word(t, a) = (M[t][a] << 8) | (M[t-1][a] << 24); rows[] is shifted by one, so rows[t] is M[t-1].
         // Four lanes share a step pair: they fetch its three model rows and each writes the entries of one b.
-        struct ModelRows { uint32_t r0, r1, r2; };
+        struct ModelRows { uint32_t r0, r1, r2, sel_second, entries; };
         auto fetch_rows = [&](int64_t p0) -> ModelRows {
-            const uint32_t* r = rows + p0 + 2 * my_pair;
-            return ModelRows{r[0], r[1], r[2]};
+            const uint4 mine = lane_consts[lane8 >> 3];
+            const uint32_t* r = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(rows + p0) + mine.z);
+            return ModelRows{r[0], r[1], r[2], mine.x, mine.y};
         };
         auto build_tables = [&](const ModelRows r) {
-            const uint32_t second = __builtin_amdgcn_perm(r.r1, r.r2, sel_second);
-            const lds_words_out_t out = (lds_words_out_t)(uintptr_t)my_entries_addr;
+            const uint32_t second = __builtin_amdgcn_perm(r.r1, r.r2, r.sel_second);
+            const lds_words_out_t out = (lds_words_out_t)(uintptr_t)(table_base + r.entries);
 #pragma unroll
             for (int a = 0; a < 4; a++) out[a] = u32x2{__builtin_amdgcn_perm(r.r0, r.r1, word_selector(a)), second};
         };
-        expand(fetch_symbols(p_lo), p_lo);
+        LazySymbols z;
+        fetch_symbols(p_lo, z);
+        expand_all(C, z, std::make_integer_sequence<int, 16>{});       // -> C[16..32): the first chunk's lower half after the slide
         // The global loads of a chunk (12 B of model rows and 8 B of symbols per lane) are issued at the END of the chunk
-        // before it and consumed at its top: no register carries them across the 16 step pairs (held there they cost six
-        // VGPRs, i.e. scratch at 96), and the latency that is exposed this way is covered by the other four waves of
-        // the SIMD (measured: 2.12 ms against 2.16 ms with the loads issued a whole chunk ahead).
+        // before it and consumed at its top: no register carries them across the windows, and the latency that is
+        // exposed this way is covered by the other four waves of the SIMD (measured in round 1: 2.12 ms against 2.16 ms
+        // with the loads issued a whole chunk ahead).
         ModelRows next_rows = fetch_rows(p_lo);
-        uint3 next_symbols = fetch_symbols(p_lo + 32);
+        fetch_symbols(p_lo + 32, z);
 
+        bool aborted = false;              // wave-uniform
+        // one bit per chunk: may the chunk look for hits every four steps only (ssv_chunk_flags)?  never with separators.
+        // The word of the current 1024 rows and, loaded a whole block ahead, the next one: the test never waits for memory
+        uint32_t safe_now = safe_chunks ? safe_chunks[p_lo >> 10] : 0u;
+        uint32_t safe_next = safe_chunks ? safe_chunks[(p_lo >> 10) + 1] : 0u;
         for (int64_t p0 = p_lo; p0 < p_hi; p0 += kChunkRows) {
+            if ((p0 & 1023) == 0 && p0 != p_lo) {
+                safe_now = safe_next;
+                safe_next = safe_chunks ? safe_chunks[(p0 >> 10) + 1] : 0u;
+            }
             // abort: a device word, read past the caches every 2048 rows (never on a wave's first chunk, so
             // short models pay nothing)
             if (abort_flag && ((p0 & 2047) == 0) && p0 != p_lo &&
-                __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+                __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { aborted = true; break; }
             build_tables(next_rows);
             // slide the window by 32 symbols
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-            expand(next_symbols, p0 + 32);
-
-            step_pairs<0>(x, x2, C, sink, staged, (uint32_t)p0, d0, lane, std::make_integer_sequence<int, kChunkPairs>{});
-            asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the step pairs
+            const bool safe = (safe_now >> ((uint32_t)(p0 >> 5) & 31u)) & 1u;
+            step_windows(x, x2, C, z, safe, sink, staged, (uint32_t)p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
+            asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the windows
             next_rows = fetch_rows(p0 + kChunkRows);              // rows[] has kModelSlack words behind the model
-            next_symbols = fetch_symbols(p0 + kChunkRows + 32);
+            fetch_symbols(p0 + kChunkRows + 32, z);
         }
-        if (p_hi == (int64_t)nrows_padded) {
-            // the high cells run one row behind: one more step gives them the model's last row
+        if (!aborted && p_hi == (int64_t)nrows_padded) {
+            // the high cells run one row behind: one more step gives them the model's last row (the window's other
+            // three steps add padding rows, which score 0)
             build_tables(next_rows);                               // fetched for p_hi by the last chunk
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-            step_pair<0>(x, x2, C, sink, staged, (uint32_t)p_hi, d0, lane);
+            expand_for_window<0>(C, z);
+            step_window<0>(x, x2, C, true, sink, staged, (uint32_t)p_hi, d0, std::make_integer_sequence<int, kRegs>{});
         }
     }   // this wave's tile
 
