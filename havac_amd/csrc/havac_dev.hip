@@ -87,6 +87,11 @@ struct havac_ssv_ctx {
     int device = 0;
     uint32_t* rows8 = nullptr; size_t rows8_rows = 0;   // padded copy of the model
     uint32_t* chunk_flags = nullptr; size_t chunk_flag_words = 0;   // one bit per 32-row chunk: hit test every four steps allowed
+    // work distribution of the persistent kernel (ssv_kernels.hip.h, SsvLaunch)
+    uint32_t* tickets = nullptr;                                    // kTicketCounters counters + the fault word
+    uint32_t* block_flags = nullptr; size_t block_flag_tiles = 0;   // row-split launches: row blocks finished, per tile
+    uint32_t* block_state = nullptr; size_t block_state_tiles = 0;  // row-split launches: 16 x 64 scores per tile
+    int resident_blocks = 0;                                        // blocks the device holds at once (5 per CU)
     const uint16_t* pair_mask = nullptr;                // optional separator bitmap (boundary mode), caller-owned
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     uint64_t* sort_alt = nullptr; size_t sort_alt_count = 0;
@@ -116,7 +121,15 @@ extern "C" int havac_ssv_ctx_create(havac_ssv_ctx** out) {
     auto fail = [&](int code) { havac_ssv_ctx_destroy(c); return code; };
     if (hipGetDevice(&c->device) != hipSuccess) return fail(HAVAC_E_NO_DEVICE);
     if (hipMalloc(&c->d_count, sizeof(unsigned long long)) != hipSuccess) return fail(HAVAC_E_NOMEM);
-    if (hipHostMalloc(&c->h_count, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return fail(HAVAC_E_NOMEM);
+    if (hipMalloc(&c->tickets, (kTicketCounters + 1) * kTicketStride * sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_NOMEM);
+    if (hipMemset(c->tickets, 0, (kTicketCounters + 1) * kTicketStride * sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return fail(HAVAC_E_NO_DEVICE);
+        c->resident_blocks = prop.multiProcessorCount * kBlocksPerCu;
+    }
+    if (hipHostMalloc(&c->h_count, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return fail(HAVAC_E_NOMEM);
+    c->h_count[0] = c->h_count[1] = 0;
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) return fail(HAVAC_E_RUNTIME);
     *out = c;
@@ -127,6 +140,9 @@ extern "C" void havac_ssv_ctx_destroy(havac_ssv_ctx* c) {
     if (!c) return;
     if (c->rows8) (void)hipFree(c->rows8);
     if (c->chunk_flags) (void)hipFree(c->chunk_flags);
+    if (c->tickets) (void)hipFree(c->tickets);
+    if (c->block_flags) (void)hipFree(c->block_flags);
+    if (c->block_state) (void)hipFree(c->block_state);
     if (c->sort_tmp) (void)hipFree(c->sort_tmp);
     if (c->sort_alt) (void)hipFree(c->sort_alt);
     if (c->d_count) (void)hipFree(c->d_count);
@@ -226,19 +242,50 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     unsigned row_bits = 1, seg_bits = 1;
     while ((1u << row_bits) < t.nrows_padded + 2u) row_bits++;
     while ((1ull << seg_bits) < nsymbols / HAVAC_SEGMENT_COLUMNS) seg_bits++;
-    HIP_TRY(c->err, hipEventRecord(c->ev[1], stream));
+    // ---- how the tiles are handed out (ssv_kernels.hip.h, "work distribution") ----
+    SsvLaunch L{};
+    L.nsymbols = (int64_t)nsymbols; L.nrows_padded = t.nrows_padded;
+    L.first_diag = t.first_diag; L.tile_begin = tb; L.ntiles = te - tb;
+    L.col_begin = (int64_t)col_begin; L.col_end = (int64_t)col_end;
+    L.hit_capacity = hit_capacity; L.row_bits = row_bits;
+    // Tall tiles that barely outnumber the wave slots are cut into row blocks (C3 as stated: 5,130 tiles of 503,329
+    // rows on 5,120 slots ran a second, nearly empty round); everything else is one item per tile.
+    const uint64_t slots = (uint64_t)c->resident_blocks * kWavesPerBlock;
+    const bool split = te > tb && L.ntiles < kSplitBelowRounds * slots && t.nrows_padded >= 2 * kRowsPerBlock;
+    uint32_t nblocks = 0;
     if (te > tb) {
-        // one tile per wave: C2 is ~12 rounds of what the chip holds at once, and the hardware's block scheduler evens
-        // out the CUs (waves that walk several tiles in a fixed order were 3-18 % slower)
-        uint32_t nblocks = (te - tb + kWavesPerBlock - 1) / kWavesPerBlock;
-        hipLaunchKernelGGL(ssv_diag_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream,
-                           d_sequence, (int64_t)nsymbols, (const uint32_t*)c->rows8, t.nrows_padded, t.first_diag,
-                           tb, te, (int64_t)col_begin, (int64_t)col_end, d_hits, c->d_count,
-                           hit_capacity, d_abort_flag, c->pair_mask, row_bits,
-                           c->pair_mask ? (const uint32_t*)nullptr : (const uint32_t*)c->chunk_flags);
+        L.nitems = L.ntiles;
+        if (split) {
+            if (c->block_flag_tiles < L.ntiles) {
+                if (c->block_flags) (void)hipFree(c->block_flags);
+                if (c->block_state) (void)hipFree(c->block_state);
+                c->block_flags = c->block_state = nullptr; c->block_flag_tiles = c->block_state_tiles = 0;
+                HIP_TRY(c->err, hipMalloc(&c->block_flags, (size_t)L.ntiles * sizeof(uint32_t)));
+                HIP_TRY(c->err, hipMalloc(&c->block_state, (size_t)L.ntiles * kRegs * 64 * sizeof(uint32_t)));
+                c->block_flag_tiles = c->block_state_tiles = L.ntiles;
+            }
+            L.rows_per_block = kRowsPerBlock;
+            const uint64_t nblocks_rows = (t.nrows_padded + kRowsPerBlock - 1) / kRowsPerBlock;
+            L.nitems = (uint32_t)(nblocks_rows * L.ntiles);
+        }
+        const uint64_t want_blocks = ((uint64_t)L.nitems + kWavesPerBlock - 1) / kWavesPerBlock;
+        nblocks = (uint32_t)(split ? std::min<uint64_t>(want_blocks, (uint64_t)c->resident_blocks) : want_blocks);
+        if (split) {
+            HIP_TRY(c->err, hipMemsetD32Async((hipDeviceptr_t)c->block_flags, 0, (size_t)L.ntiles, stream));
+            // the ticket counter starts behind the items the waves take without drawing (their own index)
+            HIP_TRY(c->err, hipMemsetD32Async((hipDeviceptr_t)c->tickets, (int)(nblocks * kWavesPerBlock), kTicketStride, stream));
+        }
     }
+    HIP_TRY(c->err, hipEventRecord(c->ev[1], stream));
+    if (te > tb)
+        hipLaunchKernelGGL(ssv_diag_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream,
+                           d_sequence, (const uint32_t*)c->rows8, c->pair_mask ? (const uint32_t*)nullptr : (const uint32_t*)c->chunk_flags,
+                           c->pair_mask, d_abort_flag, d_hits, c->d_count, c->tickets, c->block_flags, c->block_state,
+                           c->tickets + kTicketCounters * kTicketStride, L);
     HIP_TRY(c->err, hipEventRecord(c->ev[2], stream));
     HIP_TRY(c->err, hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    // the kernel's fault word (a row-block hand-off that never came): never expected, but never waited for silently either
+    HIP_TRY(c->err, hipMemcpyAsync(c->h_count + 1, c->tickets + kTicketCounters * kTicketStride, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(c->err, hipGetLastError());
     c->pending = true; c->stream = stream; c->d_hits = d_hits; c->hit_capacity = hit_capacity;
     c->row_bits = row_bits;
@@ -283,6 +330,11 @@ extern "C" int havac_ssv_finish(havac_ssv_ctx* c, uint64_t* hit_count_out) {
     HIP_TRY(c->err, hipSetDevice(c->device));
     HIP_TRY(c->err, hipStreamSynchronize(c->stream));
     uint64_t found = *c->h_count;
+    if ((uint32_t)c->h_count[1] != 0) {
+        (void)hipMemsetAsync(c->tickets + kTicketCounters * kTicketStride, 0, sizeof(uint32_t), c->stream);
+        c->err = "the SSV kernel gave up waiting for a row block of a tile (work-queue fault)";
+        return HAVAC_E_RUNTIME;
+    }
     uint64_t stored = found < c->hit_capacity ? found : c->hit_capacity;
     int rc = sort_keys(c, c->d_hits, stored, c->stream, c->key_bits);
     if (rc) return rc;

@@ -498,22 +498,47 @@ __device__ __forceinline__ void step_windows(uint32_t (&a)[kRegs], uint32_t (&b)
 // yields (row_t[a] << 8) | (row_tm1[a] << 24)
 __device__ __forceinline__ uint32_t word_selector(uint32_t a) { return 0x040c000cu + a * 0x01000100u; }
 
+// ---- work distribution ------------------------------------------------------------------------------------------------
+// An item is a tile (2048 diagonals): one per wave, four per block, handed out by the hardware's block scheduler.
+// When tall tiles are too few to balance that way (C3 as stated: 5,130 tiles of 503,329 rows on 5,120 wave slots: a
+// second, nearly empty round), an item is ONE ROW BLOCK of a tile and the kernel is persistent: as many blocks as the
+// chip holds (5 per CU), whose waves draw items from a ticket counter until none is left.  The wave that finishes rows
+// [b R, (b+1) R) of a tile leaves its 16 score registers in global memory and raises the tile's block count; the wave
+// that draws the next row block of that tile picks them up.  Tickets are drawn in row-block-major order, so the block a
+// wave waits for was drawn earlier and is held by a wave that is running: the wait always ends.
+struct SsvLaunch {                // the scalars of a launch (the pointers are kernel arguments of their own: only
+                                  // `const T* __restrict__` arguments are read with scalar loads)
+    int64_t nsymbols; uint32_t nrows_padded;
+    int64_t first_diag; uint32_t tile_begin, ntiles;
+    int64_t col_begin, col_end;
+    uint64_t hit_capacity; uint32_t row_bits;
+    uint32_t nitems;              // tiles, or tiles x row blocks
+    uint32_t rows_per_block;      // 0: tiles are not split by rows (an item is a tile); else a multiple of 1024
+};
+constexpr int kTicketStride = 16;          // the ticket counter and the fault word sit in cache lines of their own
+constexpr int kTicketCounters = 1;
+constexpr int kBlocksPerCu = 5;            // 5 blocks of 4 waves = 5 waves per SIMD
+constexpr uint32_t kRowsPerBlock = 2048;   // rows of a row block (a multiple of 1024: the chunk-flag words)
+constexpr uint64_t kSplitBelowRounds = 8;  // split by rows when there are fewer tiles than this many rounds of wave slots
+constexpr uint32_t kHandoffSpins = 1u << 22;
+
 // 5 waves per SIMD: 96 VGPRs.  cur 16 + nxt 16 + 32 match words in flight + ~19 window addresses + 4 prepared symbol words.
 __global__ __launch_bounds__(64 * kWavesPerBlock, 5)
-void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, const uint32_t* __restrict__ rows,
-                     const uint32_t nrows_padded, const int64_t first_diag, const uint32_t tile_begin,
-                     const uint32_t tile_end, const int64_t col_begin, const int64_t col_end,
-                     uint64_t* __restrict__ hits, unsigned long long* __restrict__ hit_count,
-                     const uint64_t hit_capacity, const uint32_t* __restrict__ abort_flag,
-                     const uint16_t* __restrict__ pair_mask, const uint32_t row_bits,
-                     const uint32_t* __restrict__ safe_chunks) {
+void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
+                     const uint32_t* __restrict__ safe_chunks, const uint16_t* __restrict__ pair_mask,
+                     const uint32_t* abort_flag, uint64_t* __restrict__ hits, unsigned long long* hit_count,
+                     uint32_t* tickets,          // ncounters words, kTicketStride words apart
+                     uint32_t* block_flags,      // per tile of this launch: row blocks finished
+                     uint32_t* block_state,      // per tile: 16 x 64 scores handed from one row block to the next
+                     uint32_t* fault,            // raised when a wait for a row block ran out (never expected)
+                     const SsvLaunch L) {
     __shared__ WaveLds wave_lds[kWavesPerBlock];
 
     const uint32_t lane = threadIdx.x & 63;
     // readfirstlane: everything derived from the tile index is wave-uniform (SALU branches, scalar address math)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds* const lds = &wave_lds[wave];
-    const HitSink sink{hits, hit_count, hit_capacity, lds, col_begin, col_end, row_bits};
+    const HitSink sink{hits, hit_count, L.hit_capacity, lds, L.col_begin, L.col_end, L.row_bits};
     uint32_t staged = 0;          // wave-uniform
 
     // LDS byte address of this wave's tables (a multiple of 128: code*8 is OR-ed into it)
@@ -534,18 +559,46 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
         *(lds_words_out_t)(uintptr_t)(table_base + my_pair * kPairStride + kOutsideCode) = u32x2{outside, outside};
     }
 
-    const uint32_t tile = tile_begin + blockIdx.x * kWavesPerBlock + wave;
-    const int64_t d0 = first_diag + (int64_t)tile * kTileDiags;     // wave's first diagonal
-    // steps whose cells of this tile can lie inside the matrix
-    int64_t p_lo = -d0 - kTileDiags;                                // first chunk touching column >= 0
-    if (p_lo < 0) p_lo = 0;
-    int64_t p_hi = col_end - d0;                                    // first chunk entirely right of the shard's columns
-    if (p_hi > (int64_t)nrows_padded) p_hi = nrows_padded;
-    // no early return: every wave of the block meets the others at the final flush
-    if (tile < tile_end && p_lo < p_hi) {
+    // ---- one item: rows [row_begin, row_end) of tile `tile_in_launch` ----------------------------------------------
+    auto run_item = [&](const uint32_t item) -> bool {        // false: stop (abort requested, or a hand-off never came)
+        uint32_t tile_in_launch = item, block = 0;
+        if (L.rows_per_block) { block = item / L.ntiles; tile_in_launch = item - block * L.ntiles; }
+        const uint32_t tile = L.tile_begin + tile_in_launch;
+        const int64_t d0 = L.first_diag + (int64_t)tile * kTileDiags;     // wave's first diagonal
+        // steps whose cells of this tile can lie inside the matrix
+        int64_t p_lo = -d0 - kTileDiags;                                // first chunk touching column >= 0
+        if (p_lo < 0) p_lo = 0;
+        int64_t p_hi = L.col_end - d0;                                  // first chunk entirely right of the shard's columns
+        if (p_hi > (int64_t)L.nrows_padded) p_hi = L.nrows_padded;
+        int64_t p_begin = p_lo, p_end = p_hi;                           // this item's share of them
+        if (L.rows_per_block) {
+            const int64_t b0 = (int64_t)block * L.rows_per_block;
+            if (p_begin < b0) p_begin = b0;
+            if (p_end > b0 + L.rows_per_block) p_end = b0 + L.rows_per_block;
+        }
+        if (p_begin >= p_end) return true;
+
         uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_window)
+        uint32_t* const state = block_state + (size_t)tile_in_launch * (kRegs * 64) + lane;
+        if (p_begin > p_lo) {
+            // the rows above belong to the previous row block of this tile: wait for it, take over its scores
+            uint32_t spins = 0;
+            while (__hip_atomic_load(block_flags + tile_in_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < block) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins == kHandoffSpins) {
+                    if (lane == 0) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
-        for (int i = 0; i < kRegs; i++) x[i] = x2[i] = kScoreZero;
+            for (int i = 0; i < kRegs; i++) x[i] = state[i * 64];
+        } else {
+#pragma unroll
+            for (int i = 0; i < kRegs; i++) x[i] = kScoreZero;
+        }
+#pragma unroll
+        for (int i = 0; i < kRegs; i++) x2[i] = kScoreZero;
 
         // Window of the current chunk, symbol positions [j, j+64) with j = d0 + 32 lane + p0 (see LazySymbols)
         uint32_t C[32];
@@ -553,9 +606,9 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
         // the wave's 512 bytes are consecutive: a uniform base and the lane's byte offset.
         auto fetch_symbols = [&](int64_t rel, LazySymbols& z) {
             const int64_t first = d0 + rel;                               // the wave's first position
-            const bool edge = (first < 0) || (first + kTileDiags > nsymbols);
-            const uint8_t* const base = seq + (first >> 2);               // only dereferenced for lanes inside [0, N)
-            const int64_t lo = -first, hi = nsymbols - first;             // positions relative to `first` that are inside
+            const bool edge = (first < 0) || (first + kTileDiags > L.nsymbols);
+            const uint8_t* const base = seq + (first >> 2);             // only dereferenced for lanes inside [0, N)
+            const int64_t lo = -first, hi = L.nsymbols - first;           // positions relative to `first` that are inside
             z.valid_lo = __builtin_amdgcn_readfirstlane((int32_t)(lo < 0 ? 0 : (lo > 4096 ? 4096 : lo)));
             z.valid_hi = __builtin_amdgcn_readfirstlane((int32_t)(hi < 0 ? 0 : (hi > 4096 ? 4096 : hi)));
             z.lane8 = lane8;
@@ -584,29 +637,28 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
             for (int a = 0; a < 4; a++) out[a] = u32x2{__builtin_amdgcn_perm(r.r0, r.r1, word_selector(a)), second};
         };
         LazySymbols z;
-        fetch_symbols(p_lo, z);
+        fetch_symbols(p_begin, z);
         expand_all(C, z, std::make_integer_sequence<int, 16>{});       // -> C[16..32): the first chunk's lower half after the slide
         // The global loads of a chunk (12 B of model rows and 8 B of symbols per lane) are issued at the END of the chunk
         // before it and consumed at its top: no register carries them across the windows, and the latency that is
         // exposed this way is covered by the other four waves of the SIMD (measured in round 1: 2.12 ms against 2.16 ms
         // with the loads issued a whole chunk ahead).
-        ModelRows next_rows = fetch_rows(p_lo);
-        fetch_symbols(p_lo + 32, z);
+        ModelRows next_rows = fetch_rows(p_begin);
+        fetch_symbols(p_begin + 32, z);
 
-        bool aborted = false;              // wave-uniform
+        bool go_on = true;                 // wave-uniform
         // one bit per chunk: may the chunk look for hits every four steps only (ssv_chunk_flags)?  never with separators.
         // The word of the current 1024 rows and, loaded a whole block ahead, the next one: the test never waits for memory
-        uint32_t safe_now = safe_chunks ? safe_chunks[p_lo >> 10] : 0u;
-        uint32_t safe_next = safe_chunks ? safe_chunks[(p_lo >> 10) + 1] : 0u;
-        for (int64_t p0 = p_lo; p0 < p_hi; p0 += kChunkRows) {
-            if ((p0 & 1023) == 0 && p0 != p_lo) {
+        uint32_t safe_now = safe_chunks ? safe_chunks[p_begin >> 10] : 0u;
+        uint32_t safe_next = safe_chunks ? safe_chunks[(p_begin >> 10) + 1] : 0u;
+        for (int64_t p0 = p_begin; p0 < p_end; p0 += kChunkRows) {
+            if ((p0 & 1023) == 0 && p0 != p_begin) {
                 safe_now = safe_next;
                 safe_next = safe_chunks ? safe_chunks[(p0 >> 10) + 1] : 0u;
             }
-            // abort: a device word, read past the caches every 2048 rows (never on a wave's first chunk, so
-            // short models pay nothing)
-            if (abort_flag && ((p0 & 2047) == 0) && p0 != p_lo &&
-                __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { aborted = true; break; }
+            // abort: a device word, read past the caches every 2048 rows inside an item (and between items, below)
+            if (abort_flag && ((p0 & 2047) == 0) && p0 != p_begin &&
+                __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { go_on = false; break; }
             build_tables(next_rows);
             // slide the window by 32 symbols
 #pragma unroll
@@ -617,20 +669,43 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
             next_rows = fetch_rows(p0 + kChunkRows);              // rows[] has kModelSlack words behind the model
             fetch_symbols(p0 + kChunkRows + 32, z);
         }
-        if (!aborted && p_hi == (int64_t)nrows_padded) {
+        if (!go_on) return false;
+        if (p_end == (int64_t)L.nrows_padded) {
             // the high cells run one row behind: one more step gives them the model's last row (the window's other
             // three steps add padding rows, which score 0)
-            build_tables(next_rows);                               // fetched for p_hi by the last chunk
+            build_tables(next_rows);                               // fetched for p_end by the last chunk
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
             expand_for_window<0>(C, z);
-            step_window<0>(x, x2, C, true, sink, staged, (uint32_t)p_hi, d0, std::make_integer_sequence<int, kRegs>{});
+            step_window<0>(x, x2, C, true, sink, staged, (uint32_t)p_end, d0, std::make_integer_sequence<int, kRegs>{});
+        } else if (p_end < p_hi) {
+            // the tile goes on in the next row block: hand the scores over (release: the stores, then the count)
+#pragma unroll
+            for (int i = 0; i < kRegs; i++) state[i * 64] = x[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) __hip_atomic_store(block_flags + tile_in_launch, block + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-    }   // this wave's tile
+        return true;
+    };
+
+    // ---- items --------------------------------------------------------------------------------------------------------
+    // Tiles that are not split: one tile per wave, one block per four tiles -- the hardware's block scheduler hands out
+    // the work (a drawn ticket per tile costs more than it balances: the waves of a round finish together, and
+    // thousands of returning atomics on a few words then take microseconds: measured +4 to +7 us per tile).
+    // Row blocks: drawn in row-block-major order from ONE counter; a wave's first item is its own index (the host
+    // starts the counter at the number of waves), later ones are drawn when the item before is done -- the items are
+    // long (~200 us), and after the first round the waves come back one after the other, not together.
+    uint32_t item = blockIdx.x * kWavesPerBlock + wave;         // wave-uniform
+    while (item < L.nitems) {
+        if (L.rows_per_block && abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+        if (!run_item(item) || L.rows_per_block == 0) break;
+        uint32_t got = 0;
+        if (lane == 0) got = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        item = __builtin_amdgcn_readfirstlane(got);
+    }
 
     // What is still staged goes out with ONE returning atomic per block, not per wave: the single counter word
-    // sustains ~90 returning atomics per microsecond chip-wide, and with one per wave every model shorter than ~200
-    // rows was bound by that rate, not by the VALU (48,836 tiles with a hit each = 0.55 ms on C2's 100 Mbp).
+    // sustains ~90 returning atomics per microsecond chip-wide.
     __shared__ uint32_t block_staged[kWavesPerBlock];
     __shared__ unsigned long long block_base;
     if (lane == 0) block_staged[wave] = staged;
@@ -644,7 +719,7 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const int64_t nsymbols, co
     unsigned long long base = block_base;
     for (uint32_t w = 0; w < wave; w++) base += block_staged[w];
     for (uint32_t i = lane; i < staged; i += 64)
-        if (base + i < hit_capacity) hits[base + i] = lds->stage[i];
+        if (base + i < L.hit_capacity) hits[base + i] = lds->stage[i];
 }
 
 // ---------------------------------------------------------------------------
