@@ -224,6 +224,12 @@ struct HitSink {
     uint32_t row_bits;             // width of the row field of the sort key
 };
 
+// A staged record is (row << 40 | column): two scalar instructions in the slow path; the sort key (a division by
+// 12288 and three shifts) is made here, 64 records per instruction.
+__device__ __forceinline__ uint64_t staged_to_key(uint64_t staged_record, uint32_t row_bits) {
+    return hit_key((uint32_t)(staged_record >> 40), staged_record & ((1ull << 40) - 1ull), row_bits);
+}
+
 __device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t staged) {
     if (staged == 0) return 0;
     const uint32_t lane = __lane_id();
@@ -235,7 +241,7 @@ __device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t sta
     base = ((unsigned long long)hi << 32) | lo;
     for (uint32_t i = lane; i < staged; i += 64) {
         const unsigned long long idx = base + i;
-        if (idx < sink.hit_capacity) sink.hits[idx] = sink.lds->stage[i];
+        if (idx < sink.hit_capacity) sink.hits[idx] = staged_to_key(sink.lds->stage[i], sink.row_bits);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     return 0;
@@ -246,21 +252,25 @@ __device__ __noinline__ uint32_t flush_full(const HitSink sink, uint32_t staged)
     return flush_hits(sink, __builtin_amdgcn_readfirstlane(staged));
 }
 
-// Two int16 saturating adds on the scalar unit (the slow path's copy of v_pk_add_i16 ... clamp).
-__device__ __forceinline__ uint32_t scalar_sat_add_pk16(uint32_t a, uint32_t b) {
-    int lo = (int)(short)(a & 0xffffu) + (int)(short)(b & 0xffffu);
-    int hi = (int)(short)(a >> 16) + (int)(short)(b >> 16);
-    lo = lo < -32768 ? -32768 : (lo > 32767 ? 32767 : lo);
-    hi = hi < -32768 ? -32768 : (hi > 32767 ? 32767 : hi);
-    return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+// The slow path's copy of one half of v_pk_add_i16 ... clamp, on the scalar unit: the cell and its match score are kept
+// in the HIGH halves of 32-bit values, so that int16 saturation is int32 saturation (s_add_i32 reports the overflow).
+// A crossed cell reads 0x7fffffff (no regular value does: those have a zero low half), a cell at score 0 0x80000000.
+__device__ __forceinline__ int32_t scalar_sat_add(int32_t a, int32_t b) {
+    const int32_t saturated = (b >> 31) ^ INT32_MAX;      // where the sum goes if it overflows: the sign of b decides
+    int32_t d;
+    asm("s_add_i32 %0, %1, %2\n\ts_cselect_b32 %0, %3, %0" : "=&s"(d) : "s"(a), "s"(b), "s"(saturated) : "scc");
+    return d;
 }
 
-// One record of the slow path: cell (row, column), wave-uniform.
+// One record of the slow path: cell (row, column), wave-uniform.  Staged as (row << 40 | column) by lane 0.
 __device__ __forceinline__ uint32_t emit_cell(const HitSink& sink, uint32_t staged, uint32_t row, int64_t column) {
-    if (column >= sink.col_begin && column < sink.col_end) {      // halo columns belong to the neighbouring shard
-        const auto lds = (__attribute__((address_space(3))) WaveLds*)sink.lds;
-        const uint64_t key = hit_key(row, (uint64_t)column, sink.row_bits);
-        if (__lane_id() == 0) lds->stage[staged] = key;
+    // halo columns belong to the neighbouring shard: one unsigned comparison of (column - col_begin) with the span
+    if ((uint64_t)(column - sink.col_begin) < (uint64_t)(sink.col_end - sink.col_begin)) {
+        const uint64_t record = ((uint64_t)row << 40) | (uint64_t)column;
+        const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint64_t*)sink.lds->stage + staged * 8;
+        uint64_t saved_exec;        // one lane stores: exec = lane 0 for the one instruction
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b64 %1, %2\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved_exec) : "v"(addr), "v"(record) : "memory");
         staged++;
         if (staged == kHitStage) staged = flush_full(sink, staged);
     }
@@ -349,43 +359,86 @@ __device__ __forceinline__ void window_inputs(uint32_t l, const uint32_t (&cur)[
                  : "v"(cur[I]), "v"(C[2 * Q + I]), "v"(C[2 * Q + 1 + I]), "s"(l));
 }
 
+// The marked registers of lane l as a 16-bit mask.  Per register: read the lane, AND with the mark bits (SCC = any
+// set), select the register's bit on SCC, OR it in -- four instructions; hipcc makes five of the same in C++.
+__device__ __forceinline__ uint32_t marked_registers(const uint32_t (&n)[kRegs], uint32_t l) {
+    static_assert(kRegs == 16, "the asm below names sixteen registers");
+    uint32_t mask = 0, t;
+    asm volatile("v_readlane_b32 %1, %3, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 1, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %4, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 2, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %5, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 4, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %6, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 8, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %7, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 16, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %8, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 32, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %9, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 64, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %10, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 128, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %11, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 256, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %12, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 512, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %13, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 1024, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %14, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 2048, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %15, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 4096, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %16, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 8192, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %17, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 16384, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 "v_readlane_b32 %1, %18, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 32768, 0\n\ts_or_b32 %0, %0, %1\n\t"
+                 : "+s"(mask), "=&s"(t)
+                 : "s"(l), "v"(n[0]), "v"(n[1]), "v"(n[2]), "v"(n[3]), "v"(n[4]), "v"(n[5]), "v"(n[6]), "v"(n[7]),
+                   "v"(n[8]), "v"(n[9]), "v"(n[10]), "v"(n[11]), "v"(n[12]), "v"(n[13]), "v"(n[14]), "v"(n[15])
+                 : "scc");
+    return mask;
+}
+
 // Lane l of score register r (0..15, wave-uniform) := s.  ONE asm statement that names all 16 registers and branches
-// inside: written as sixteen conditional C++ statements, the merge of the sixteen paths makes hipcc treat the register
+// inside (a binary tree on r: four compares): written as sixteen conditional C++ statements, the merge of the sixteen paths makes hipcc treat the register
 // set as one 512-bit value that it copies and spills as a whole in the hot loop (1.2 KB of scratch).
 __device__ __forceinline__ void write_score_lane(uint32_t (&n)[kRegs], uint32_t s, uint32_t l, uint32_t r) {
     static_assert(kRegs == 16, "the asm below names sixteen registers");
     asm volatile("s_mov_b32 m0, %[l]\n\t"
-                 "s_cmp_eq_u32 %[r], 0\n\ts_cbranch_scc1 .Lhavac_w0_%=\n\t"
-                 "s_cmp_eq_u32 %[r], 1\n\ts_cbranch_scc1 .Lhavac_w1_%=\n\t"
-                 "s_cmp_eq_u32 %[r], 2\n\ts_cbranch_scc1 .Lhavac_w2_%=\n\t"
-                 "s_cmp_eq_u32 %[r], 3\n\ts_cbranch_scc1 .Lhavac_w3_%=\n\t"
-                 "s_cmp_eq_u32 %[r], 4\n\ts_cbranch_scc1 .Lhavac_w4_%=\n\t"
-                 "s_cmp_eq_u32 %[r], 5\n\ts_cbranch_scc1 .Lhavac_w5_%=\n\t"
-                 "s_cmp_eq_u32 %[r], 6\n\ts_cbranch_scc1 .Lhavac_w6_%=\n\t"
-                 "s_cmp_eq_u32 %[r], 7\n\ts_cbranch_scc1 .Lhavac_w7_%=\n\t"
-                 "s_cmp_eq_u32 %[r], 8\n\ts_cbranch_scc1 .Lhavac_w8_%=\n\t"
-                 "s_cmp_eq_u32 %[r], 9\n\ts_cbranch_scc1 .Lhavac_w9_%=\n\t"
-                 "s_cmp_eq_u32 %[r], 10\n\ts_cbranch_scc1 .Lhavac_w10_%=\n\t"
-                 "s_cmp_eq_u32 %[r], 11\n\ts_cbranch_scc1 .Lhavac_w11_%=\n\t"
-                 "s_cmp_eq_u32 %[r], 12\n\ts_cbranch_scc1 .Lhavac_w12_%=\n\t"
-                 "s_cmp_eq_u32 %[r], 13\n\ts_cbranch_scc1 .Lhavac_w13_%=\n\t"
-                 "s_cmp_eq_u32 %[r], 14\n\ts_cbranch_scc1 .Lhavac_w14_%=\n\t"
+                 "s_cmp_ge_u32 %[r], 8\n\ts_cbranch_scc1 .Lhavac_w8_16_%=\n\t"
+                 "s_cmp_ge_u32 %[r], 4\n\ts_cbranch_scc1 .Lhavac_w4_8_%=\n\t"
+                 "s_cmp_ge_u32 %[r], 2\n\ts_cbranch_scc1 .Lhavac_w2_4_%=\n\t"
+                 "s_cmp_ge_u32 %[r], 1\n\ts_cbranch_scc1 .Lhavac_w1_2_%=\n\t"
+                 "v_writelane_b32 %0, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w1_2_%=:\n\t"
+                 "v_writelane_b32 %1, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w2_4_%=:\n\t"
+                 "s_cmp_ge_u32 %[r], 3\n\ts_cbranch_scc1 .Lhavac_w3_4_%=\n\t"
+                 "v_writelane_b32 %2, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w3_4_%=:\n\t"
+                 "v_writelane_b32 %3, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w4_8_%=:\n\t"
+                 "s_cmp_ge_u32 %[r], 6\n\ts_cbranch_scc1 .Lhavac_w6_8_%=\n\t"
+                 "s_cmp_ge_u32 %[r], 5\n\ts_cbranch_scc1 .Lhavac_w5_6_%=\n\t"
+                 "v_writelane_b32 %4, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w5_6_%=:\n\t"
+                 "v_writelane_b32 %5, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w6_8_%=:\n\t"
+                 "s_cmp_ge_u32 %[r], 7\n\ts_cbranch_scc1 .Lhavac_w7_8_%=\n\t"
+                 "v_writelane_b32 %6, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w7_8_%=:\n\t"
+                 "v_writelane_b32 %7, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w8_16_%=:\n\t"
+                 "s_cmp_ge_u32 %[r], 12\n\ts_cbranch_scc1 .Lhavac_w12_16_%=\n\t"
+                 "s_cmp_ge_u32 %[r], 10\n\ts_cbranch_scc1 .Lhavac_w10_12_%=\n\t"
+                 "s_cmp_ge_u32 %[r], 9\n\ts_cbranch_scc1 .Lhavac_w9_10_%=\n\t"
+                 "v_writelane_b32 %8, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w9_10_%=:\n\t"
+                 "v_writelane_b32 %9, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w10_12_%=:\n\t"
+                 "s_cmp_ge_u32 %[r], 11\n\ts_cbranch_scc1 .Lhavac_w11_12_%=\n\t"
+                 "v_writelane_b32 %10, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w11_12_%=:\n\t"
+                 "v_writelane_b32 %11, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w12_16_%=:\n\t"
+                 "s_cmp_ge_u32 %[r], 14\n\ts_cbranch_scc1 .Lhavac_w14_16_%=\n\t"
+                 "s_cmp_ge_u32 %[r], 13\n\ts_cbranch_scc1 .Lhavac_w13_14_%=\n\t"
+                 "v_writelane_b32 %12, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w13_14_%=:\n\t"
+                 "v_writelane_b32 %13, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w14_16_%=:\n\t"
+                 "s_cmp_ge_u32 %[r], 15\n\ts_cbranch_scc1 .Lhavac_w15_16_%=\n\t"
+                 "v_writelane_b32 %14, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
+                 ".Lhavac_w15_16_%=:\n\t"
                  "v_writelane_b32 %15, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w0_%=:\n\tv_writelane_b32 %0, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w1_%=:\n\tv_writelane_b32 %1, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w2_%=:\n\tv_writelane_b32 %2, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w3_%=:\n\tv_writelane_b32 %3, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w4_%=:\n\tv_writelane_b32 %4, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w5_%=:\n\tv_writelane_b32 %5, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w6_%=:\n\tv_writelane_b32 %6, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w7_%=:\n\tv_writelane_b32 %7, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w8_%=:\n\tv_writelane_b32 %8, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w9_%=:\n\tv_writelane_b32 %9, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w10_%=:\n\tv_writelane_b32 %10, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w11_%=:\n\tv_writelane_b32 %11, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w12_%=:\n\tv_writelane_b32 %12, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w13_%=:\n\tv_writelane_b32 %13, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
-                 ".Lhavac_w14_%=:\n\tv_writelane_b32 %14, %[s], m0\n\ts_branch .Lhavac_wend_%=\n"
                  ".Lhavac_wend_%=:"
                  : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3]), "+v"(n[4]), "+v"(n[5]), "+v"(n[6]), "+v"(n[7]),
                    "+v"(n[8]), "+v"(n[9]), "+v"(n[10]), "+v"(n[11]), "+v"(n[12]), "+v"(n[13]), "+v"(n[14]), "+v"(n[15])
@@ -407,8 +460,7 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
     do {
         const uint32_t l = (uint32_t)__builtin_ctzll(lanes);
         lanes &= lanes - 1;
-        uint32_t regs = 0;                 // the lane's marked registers
-        ((regs |= (__builtin_amdgcn_readlane(nxt[I], l) & kCrossedBits) ? (1u << I) : 0u), ...);
+        uint32_t regs = marked_registers(nxt, l);
         do {
             const uint32_t r = (uint32_t)__builtin_ctz(regs);
             regs &= regs - 1;
@@ -426,18 +478,21 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
             }
             const uint32_t t0 = step0 + kWindowSteps * Q;
             const int64_t column0 = wave_diag0 + (int64_t)(32 * l + 2 * r) + (int64_t)t0;
+            int32_t low = (int32_t)(s << 16), high = (int32_t)(s & 0xffff0000u);     // the register's two cells
 #pragma unroll
             for (int k = 0; k < NSTEPS; k++) {
-                s = scalar_sat_add_pk16(s, w[k]);
-                const uint32_t f = s & kCrossedBits;
-                if (f) {
-                    if (k >= report_from) {
-                        if (f & 1u) staged = emit_cell(sink, staged, t0 + k, column0 + k);
-                        if (f >> 16) staged = emit_cell(sink, staged, t0 + k - 1, column0 + k);
-                    }
-                    s += f;
+                low = scalar_sat_add(low, (int32_t)(w[k] << 16));
+                high = scalar_sat_add(high, (int32_t)(w[k] & 0xffff0000u));
+                if (low == INT32_MAX) {           // the low cell crossed at (row t0 + k, column column0 + k)
+                    if (k >= report_from) staged = emit_cell(sink, staged, t0 + k, column0 + k);
+                    low = INT32_MIN;
+                }
+                if (high == INT32_MAX) {          // the high cell: one row behind, the same column
+                    if (k >= report_from) staged = emit_cell(sink, staged, t0 + k - 1, column0 + k);
+                    high = INT32_MIN;
                 }
             }
+            s = ((uint32_t)low >> 16) | ((uint32_t)high & 0xffff0000u);
             write_score_lane(nxt, s, l, r);
         } while (regs);
     } while (lanes);
@@ -451,15 +506,20 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
                                             bool safe, const HitSink& sink, uint32_t& staged, uint32_t step0,
                                             int64_t wave_diag0, std::integer_sequence<int, I...> regs) {
     static_assert(sizeof...(I) == kRegs, "one index per score register");
-    u32x2 m[kRegs];
-    __builtin_amdgcn_sched_barrier(0);      // no reads of this window above the previous window's last adds: no registers for them
+    constexpr int H = kRegs / 2;            // match words are read for eight registers at a time: 16 VGPRs in flight, not 32
+    // steps 4Q, 4Q+1
 #pragma unroll
-    for (int i = 0; i < kRegs; i++) m[i] = match_words<2 * Q>(C[2 * Q + i]);
-    __builtin_amdgcn_sched_barrier(0);      // all 16 reads in flight before the first add waits (hipcc otherwise staggers them)
+    for (int h = 0; h < 2; h++) {
+        u32x2 m[H];
+        __builtin_amdgcn_sched_barrier(0);      // reads stay behind the adds before them: hoisted, they cost registers the kernel does not have
 #pragma unroll
-    for (int i = 0; i < kRegs; i++) asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(nxt[i]) : "v"(cur[i]), "v"(m[i].x));
+        for (int i = 0; i < H; i++) m[i] = match_words<2 * Q>(C[2 * Q + h * H + i]);
+        __builtin_amdgcn_sched_barrier(0);      // all eight reads in flight before the first add waits (hipcc otherwise staggers them)
 #pragma unroll
-    for (int i = 0; i < kRegs; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[i]) : "v"(m[i].y));
+        for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(nxt[h * H + i]) : "v"(cur[h * H + i]), "v"(m[i].x));
+#pragma unroll
+        for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[h * H + i]) : "v"(m[i].y));
+    }
     if (!safe) {
         uint32_t any = 0;
 #pragma unroll
@@ -467,14 +527,19 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
         if (__builtin_expect(__any((any & kCrossedBits) != 0), 0))
             window_slow<Q, 2>(cur, nxt, C, any, 0, sink, staged, step0, wave_diag0, regs);
     }
-    __builtin_amdgcn_sched_barrier(0);      // the second reads stay behind the adds above (their registers are the first reads')
+    // steps 4Q+2, 4Q+3
 #pragma unroll
-    for (int i = 0; i < kRegs; i++) m[i] = match_words<2 * Q + 1>(C[2 * Q + 1 + i]);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int h = 0; h < 2; h++) {
+        u32x2 m[H];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < kRegs; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[i]) : "v"(m[i].x));
+        for (int i = 0; i < H; i++) m[i] = match_words<2 * Q + 1>(C[2 * Q + 1 + h * H + i]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < kRegs; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[i]) : "v"(m[i].y));
+        for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[h * H + i]) : "v"(m[i].x));
+#pragma unroll
+        for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[h * H + i]) : "v"(m[i].y));
+    }
     uint32_t any = 0;
 #pragma unroll
     for (int i = 0; i < kRegs; i++) any |= nxt[i];
@@ -719,7 +784,7 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
     unsigned long long base = block_base;
     for (uint32_t w = 0; w < wave; w++) base += block_staged[w];
     for (uint32_t i = lane; i < staged; i += 64)
-        if (base + i < L.hit_capacity) hits[base + i] = lds->stage[i];
+        if (base + i < L.hit_capacity) hits[base + i] = staged_to_key(lds->stage[i], L.row_bits);
 }
 
 // ---------------------------------------------------------------------------
