@@ -585,7 +585,7 @@ constexpr int kTicketCounters = 1;
 constexpr int kBlocksPerCu = 5;            // 5 blocks of 4 waves = 5 waves per SIMD
 constexpr uint32_t kRowsPerBlock = 2048;   // rows of a row block (a multiple of 1024: the chunk-flag words)
 constexpr uint64_t kSplitBelowRounds = 8;  // split by rows when there are fewer tiles than this many rounds of wave slots
-constexpr uint32_t kHandoffSpins = 1u << 22;
+constexpr uint32_t kHandoffSpins = 1u << 26;   // x ~1 us: a minute, far beyond any row block (dense-hit models take ~1 s each)
 
 // 5 waves per SIMD: 96 VGPRs.  cur 16 + nxt 16 + 32 match words in flight + ~19 window addresses + 4 prepared symbol words.
 __global__ __launch_bounds__(64 * kWavesPerBlock, 5)
@@ -649,7 +649,7 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
             // the rows above belong to the previous row block of this tile: wait for it, take over its scores
             uint32_t spins = 0;
             while (__hip_atomic_load(block_flags + tile_in_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < block) {
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(32);
                 if (++spins == kHandoffSpins) {
                     if (lane == 0) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     return false;
