@@ -236,7 +236,7 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
                        d_phmm, nrows, c->rows8, model_words);
     // separator pairs score -128 twice in a row whatever the model says: with a mask every chunk tests every two steps
     if (!c->pair_mask)
-        hipLaunchKernelGGL(ssv_chunk_flags, dim3((flag_words + 63) / 64), dim3(64), 0, stream,
+        hipLaunchKernelGGL(ssv_chunk_flags, dim3((flag_words * 32 + 63) / 64), dim3(64), 0, stream,
                            (const uint32_t*)c->rows8, t.nrows_padded, c->chunk_flags, flag_words);
     // sort key = segment | row | column in segment, each field only as wide as this problem needs
     unsigned row_bits = 1, seg_bits = 1;

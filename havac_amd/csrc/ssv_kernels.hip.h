@@ -130,25 +130,30 @@ __global__ void ssv_pad_model(const int8_t* __restrict__ phmm, uint32_t nrows,
 // below -255 whatever the symbols are.  One bit per chunk; `rows` is the padded model of ssv_pad_model.
 __global__ void ssv_chunk_flags(const uint32_t* __restrict__ rows, uint32_t nrows_padded, uint32_t* __restrict__ flags,
                                 uint32_t nwords) {
-    const uint32_t word = blockIdx.x * blockDim.x + threadIdx.x;
-    if (word >= nwords) return;
-    auto lowest = [&](uint32_t index) -> int {          // min(0, the four scores of rows[index]); 0 beyond the array
-        if (index >= nrows_padded + kModelSlack) return 0;
-        const uint32_t r = rows[index];
-        int m = 0;
-        for (int a = 0; a < 4; a++) m = min(m, (int)(int8_t)(r >> (8 * a)));
-        return m;
-    };
-    uint32_t bits = 0;
-    for (uint32_t b = 0; b < 32; b++) {
-        const uint32_t p0 = (word * 32 + b) * kChunkRows;
-        if (p0 >= nrows_padded + kChunkRows) break;
-        bool safe = true;
-        // rows p0-1 .. p0+31 are rows[p0 .. p0+32]: every run of three of them
-        for (uint32_t t = p0; t <= p0 + kChunkRows - 2 && safe; t++) safe = lowest(t) + lowest(t + 1) + lowest(t + 2) >= -255;
-        bits |= (safe ? 1u : 0u) << b;
+    // one thread per chunk, 64 chunks = two flag words per wave
+    const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p0 = chunk * kChunkRows;
+    const uint32_t limit = nrows_padded + kModelSlack;
+    bool safe = false;
+    if (chunk / 32 < nwords && p0 < nrows_padded + kChunkRows) {
+        // rows p0-1 .. p0+31 are rows[p0 .. p0+32]: the lowest score of each (at most 0; 0 beyond the array) ...
+        int lowest[kChunkRows + 1];
+#pragma unroll
+        for (int k = 0; k <= kChunkRows; k++) {
+            const uint32_t r = p0 + k < limit ? rows[p0 + k] : 0u;
+            int m = 0;
+#pragma unroll
+            for (int a = 0; a < 4; a++) m = min(m, (int)(int8_t)(r >> (8 * a)));
+            lowest[k] = m;
+        }
+        // ... and every run of three of them
+        safe = true;
+#pragma unroll
+        for (int k = 0; k + 2 <= kChunkRows; k++) safe = safe && (lowest[k] + lowest[k + 1] + lowest[k + 2] >= -255);
     }
-    flags[word] = bits;
+    const unsigned long long bits = __ballot(safe);
+    const uint32_t lane = threadIdx.x & 63, word = chunk / 32;
+    if (word < nwords && (lane & 31) == 0) flags[word] = (uint32_t)(bits >> (lane & 32));
 }
 
 // ---------------------------------------------------------------------------
@@ -583,7 +588,8 @@ struct SsvLaunch {                // the scalars of a launch (the pointers are k
 constexpr int kTicketStride = 16;          // the ticket counter and the fault word sit in cache lines of their own
 constexpr int kTicketCounters = 1;
 constexpr int kBlocksPerCu = 5;            // 5 blocks of 4 waves = 5 waves per SIMD
-constexpr uint32_t kRowsPerBlock = 2048;   // rows of a row block (a multiple of 1024: the chunk-flag words)
+constexpr uint32_t kRowsPerBlock = 8192;   // rows of a row block (a multiple of 1024: the chunk-flag words); a hand-off
+                                           // moves 2 x 4 KB per 8192 x 2048 cells
 constexpr uint64_t kSplitBelowRounds = 8;  // split by rows when there are fewer tiles than this many rounds of wave slots
 constexpr uint32_t kHandoffSpins = 1u << 26;   // x ~1 us: a minute, far beyond any row block (dense-hit models take ~1 s each)
 
@@ -644,20 +650,21 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
         if (p_begin >= p_end) return true;
 
         uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_window)
-        uint32_t* const state = block_state + (size_t)tile_in_launch * (kRegs * 64) + lane;
+        // (uniform base, lane offset added where it is used: a per-lane 64-bit pointer would sit in two VGPRs through the item)
+        uint32_t* const tile_state = block_state + (size_t)tile_in_launch * (kRegs * 64);
         if (p_begin > p_lo) {
             // the rows above belong to the previous row block of this tile: wait for it, take over its scores
             uint32_t spins = 0;
             while (__hip_atomic_load(block_flags + tile_in_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < block) {
                 __builtin_amdgcn_s_sleep(32);
                 if (++spins == kHandoffSpins) {
-                    if (lane == 0) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane8 == 0) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     return false;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
-            for (int i = 0; i < kRegs; i++) x[i] = state[i * 64];
+            for (int i = 0; i < kRegs; i++) x[i] = tile_state[i * 64 + (lane8 >> 3)];
         } else {
 #pragma unroll
             for (int i = 0; i < kRegs; i++) x[i] = kScoreZero;
@@ -682,7 +689,7 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
             uint2 w = make_uint2(0u, 0u);
             if (inside) w = *reinterpret_cast<const uint2*>(base + lane8);
             z.separators = 0;
-            if (pair_mask && inside) z.separators = pair_mask[(first >> 5) + lane];
+            if (pair_mask && inside) z.separators = pair_mask[(first >> 5) + (lane8 >> 3)];
             z.special = edge || (pair_mask && __any(z.separators != 0));
             prepare_symbols(z, w.x, w.y);
         };
@@ -746,9 +753,9 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
         } else if (p_end < p_hi) {
             // the tile goes on in the next row block: hand the scores over (release: the stores, then the count)
 #pragma unroll
-            for (int i = 0; i < kRegs; i++) state[i * 64] = x[i];
+            for (int i = 0; i < kRegs; i++) tile_state[i * 64 + (lane8 >> 3)] = x[i];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (lane == 0) __hip_atomic_store(block_flags + tile_in_launch, block + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane8 == 0) __hip_atomic_store(block_flags + tile_in_launch, block + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return true;
     };
@@ -765,7 +772,7 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
         if (L.rows_per_block && abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
         if (!run_item(item) || L.rows_per_block == 0) break;
         uint32_t got = 0;
-        if (lane == 0) got = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane8 == 0) got = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         item = __builtin_amdgcn_readfirstlane(got);
     }
 
@@ -773,7 +780,8 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
     // sustains ~90 returning atomics per microsecond chip-wide.
     __shared__ uint32_t block_staged[kWavesPerBlock];
     __shared__ unsigned long long block_base;
-    if (lane == 0) block_staged[wave] = staged;
+    const uint32_t lane_again = __lane_id();     // not kept through the items: two instructions here
+    if (lane_again == 0) block_staged[wave] = staged;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t total = 0;
@@ -783,7 +791,7 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
     __syncthreads();
     unsigned long long base = block_base;
     for (uint32_t w = 0; w < wave; w++) base += block_staged[w];
-    for (uint32_t i = lane; i < staged; i += 64)
+    for (uint32_t i = lane_again; i < staged; i += 64)
         if (base + i < L.hit_capacity) hits[base + i] = staged_to_key(lds->stage[i], L.row_bits);
 }
 

@@ -180,8 +180,23 @@ def test_havac_class_end_to_end(tmp_path, oracle):
     assert h.currentHardwareState() == 4
     hits = h.getHitsFromFinishedRun()
     assert np.array_equal(h.rawHits(), want_raw)                  # device order, element for element
-    want = havac.resolve_hits(fa, hmm, want_raw)
-    assert hits == want
+    # The resolved hits, worked out here and not by the product's resolver (host/Havac.cpp:104-187 restated in numpy):
+    # global column -> (record, position in record) through the records' end positions (each record occupies its
+    # residues plus one terminator column; a column at or beyond the last end is padding and the hit is dropped),
+    # global row -> (model, position in model) through the prefix sums of the model lengths.
+    record_lengths = [5000, 9000, 30000, 17]
+    record_ends = np.cumsum([n + 1 for n in record_lengths])        # sequenceEndPosition counts the terminator
+    model_starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    rows_w, cols_w = oracle.unpack_hits(want_raw)
+    expected = []
+    for row, col in zip(rows_w.tolist(), cols_w.tolist()):
+        if col >= record_ends[-1]:
+            continue                                                 # padding behind the last record
+        rec = int(np.searchsorted(record_ends, col, side="right"))
+        model = int(np.searchsorted(model_starts, row, side="right")) - 1
+        expected.append((col - (int(record_ends[rec - 1]) if rec else 0), rec, row - int(model_starts[model]), model))
+    assert [(x.sequencePosition, x.sequenceIndex, x.phmmPosition, x.phmmIndex) for x in hits] == expected
+    assert hits == havac.resolve_hits(fa, hmm, want_raw)          # and the free-standing resolver agrees
     # every resolved hit points into a real record and a real model
     ends = np.cumsum(lens)
     for x in hits:
