@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -248,10 +250,19 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     L.first_diag = t.first_diag; L.tile_begin = tb; L.ntiles = te - tb;
     L.col_begin = (int64_t)col_begin; L.col_end = (int64_t)col_end;
     L.hit_capacity = hit_capacity; L.row_bits = row_bits;
-    // Tall tiles that barely outnumber the wave slots are cut into row blocks (C3 as stated: 5,130 tiles of 503,329
-    // rows on 5,120 slots ran a second, nearly empty round); everything else is one item per tile.
+    // Row blocks (ssv_kernels.hip.h, "work distribution"): tiles taller than a block are cut into blocks of
+    // kRowsPerBlock rows when there are fewer of them than kSplitBelowRounds rounds of wave slots (measured, kernel
+    // only: C3 as stated 42.4 -> 54.0 TCUPS, C5 53.0 -> 54.6; blocks of 4096 / 16384 rows: 53.6 / 53.6 and 54.0 / 54.7).  (Cutting SHORT
+    // tiles to fill the last round -- C2 is 9.54 rounds -- does not pay: 2, 3, 4 row blocks per 1024-row tile took 2.20,
+    // 3.22, 4.5 ms against 2.02: a hand-off per 57 us of work, with its release and acquire, costs more than the idle slots.)
     const uint64_t slots = (uint64_t)c->resident_blocks * kWavesPerBlock;
-    const bool split = te > tb && L.ntiles < kSplitBelowRounds * slots && t.nrows_padded >= 2 * kRowsPerBlock;
+    uint32_t rows_per_block = 0;
+    if (te > tb && t.nrows_padded >= kRowsPerBlock + 1024 && L.ntiles < kSplitBelowRounds * slots) rows_per_block = kRowsPerBlock;
+    if (const char* forced = std::getenv("HAVAC_ROWS_PER_BLOCK")) {          // experiments: 0 = never split
+        rows_per_block = (uint32_t)std::atoi(forced) / kChunkRows * kChunkRows;
+        if (rows_per_block >= t.nrows_padded) rows_per_block = 0;
+    }
+    const bool split = rows_per_block != 0;
     uint32_t nblocks = 0;
     if (te > tb) {
         L.nitems = L.ntiles;
@@ -264,16 +275,14 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
                 HIP_TRY(c->err, hipMalloc(&c->block_state, (size_t)L.ntiles * kRegs * 64 * sizeof(uint32_t)));
                 c->block_flag_tiles = c->block_state_tiles = L.ntiles;
             }
-            L.rows_per_block = kRowsPerBlock;
-            const uint64_t nblocks_rows = (t.nrows_padded + kRowsPerBlock - 1) / kRowsPerBlock;
+            L.rows_per_block = rows_per_block;
+            const uint64_t nblocks_rows = (t.nrows_padded + rows_per_block - 1) / rows_per_block;
             L.nitems = (uint32_t)(nblocks_rows * L.ntiles);
         }
-        const uint64_t want_blocks = ((uint64_t)L.nitems + kWavesPerBlock - 1) / kWavesPerBlock;
-        nblocks = (uint32_t)(split ? std::min<uint64_t>(want_blocks, (uint64_t)c->resident_blocks) : want_blocks);
+        nblocks = (uint32_t)(((uint64_t)L.nitems + kWavesPerBlock - 1) / kWavesPerBlock);
         if (split) {
             HIP_TRY(c->err, hipMemsetD32Async((hipDeviceptr_t)c->block_flags, 0, (size_t)L.ntiles, stream));
-            // the ticket counter starts behind the items the waves take without drawing (their own index)
-            HIP_TRY(c->err, hipMemsetD32Async((hipDeviceptr_t)c->tickets, (int)(nblocks * kWavesPerBlock), kTicketStride, stream));
+            HIP_TRY(c->err, hipMemsetD32Async((hipDeviceptr_t)c->tickets, 0, kTicketStride, stream));
         }
     }
     HIP_TRY(c->err, hipEventRecord(c->ev[1], stream));

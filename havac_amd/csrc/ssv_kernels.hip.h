@@ -569,13 +569,13 @@ __device__ __forceinline__ void step_windows(uint32_t (&a)[kRegs], uint32_t (&b)
 __device__ __forceinline__ uint32_t word_selector(uint32_t a) { return 0x040c000cu + a * 0x01000100u; }
 
 // ---- work distribution ------------------------------------------------------------------------------------------------
-// An item is a tile (2048 diagonals): one per wave, four per block, handed out by the hardware's block scheduler.
-// When tall tiles are too few to balance that way (C3 as stated: 5,130 tiles of 503,329 rows on 5,120 wave slots: a
-// second, nearly empty round), an item is ONE ROW BLOCK of a tile and the kernel is persistent: as many blocks as the
-// chip holds (5 per CU), whose waves draw items from a ticket counter until none is left.  The wave that finishes rows
-// [b R, (b+1) R) of a tile leaves its 16 score registers in global memory and raises the tile's block count; the wave
-// that draws the next row block of that tile picks them up.  Tickets are drawn in row-block-major order, so the block a
-// wave waits for was drawn earlier and is held by a wave that is running: the wait always ends.
+// An item is a tile (2048 diagonals) or ONE ROW BLOCK of a tile: one item per wave, four per block, the blocks handed
+// out by the hardware's block scheduler.  Tall tiles are cut into row blocks of 8192 rows: as whole tiles they balance
+// badly (C3 as stated: 5,130 tiles of 503,329 rows on 5,120 wave slots: a second, nearly empty round).  The wave that finishes
+// rows [b R, (b+1) R) of a tile leaves its 16 score registers in global memory and raises the tile's block count; the
+// wave with the next row block of that tile picks them up.  Items are numbered row-block-major and a block takes its
+// four item numbers from a ticket it draws when it starts, so the row block a wave waits for is held by a block that
+// has started, whatever order blocks are dispatched in: the wait always ends.
 struct SsvLaunch {                // the scalars of a launch (the pointers are kernel arguments of their own: only
                                   // `const T* __restrict__` arguments are read with scalar loads)
     int64_t nsymbols; uint32_t nrows_padded;
@@ -590,7 +590,7 @@ constexpr int kTicketCounters = 1;
 constexpr int kBlocksPerCu = 5;            // 5 blocks of 4 waves = 5 waves per SIMD
 constexpr uint32_t kRowsPerBlock = 8192;   // rows of a row block (a multiple of 1024: the chunk-flag words); a hand-off
                                            // moves 2 x 4 KB per 8192 x 2048 cells
-constexpr uint64_t kSplitBelowRounds = 8;  // split by rows when there are fewer tiles than this many rounds of wave slots
+constexpr uint64_t kSplitBelowRounds = 64; // tall tiles are split by rows when there are fewer of them than this many rounds of wave slots
 constexpr uint32_t kHandoffSpins = 1u << 26;   // x ~1 us: a minute, far beyond any row block (dense-hit models take ~1 s each)
 
 // 5 waves per SIMD: 96 VGPRs.  cur 16 + nxt 16 + 32 match words in flight + ~19 window addresses + 4 prepared symbol words.
@@ -761,20 +761,20 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
     };
 
     // ---- items --------------------------------------------------------------------------------------------------------
-    // Tiles that are not split: one tile per wave, one block per four tiles -- the hardware's block scheduler hands out
-    // the work (a drawn ticket per tile costs more than it balances: the waves of a round finish together, and
-    // thousands of returning atomics on a few words then take microseconds: measured +4 to +7 us per tile).
-    // Row blocks: drawn in row-block-major order from ONE counter; a wave's first item is its own index (the host
-    // starts the counter at the number of waves), later ones are drawn when the item before is done -- the items are
-    // long (~200 us), and after the first round the waves come back one after the other, not together.
-    uint32_t item = blockIdx.x * kWavesPerBlock + wave;         // wave-uniform
-    while (item < L.nitems) {
-        if (L.rows_per_block && abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
-        if (!run_item(item) || L.rows_per_block == 0) break;
-        uint32_t got = 0;
-        if (lane8 == 0) got = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        item = __builtin_amdgcn_readfirstlane(got);
+    // One item per wave, four per block, the blocks handed out by the hardware's block scheduler.  Whole tiles: the item
+    // is the wave's index.  Row blocks: the BLOCK draws a ticket when it starts (one returning atomic per four items)
+    // and its waves take items 4 ticket .. 4 ticket + 3 -- the order of the items is then the order in which blocks
+    // really started, whatever order the hardware dispatched them in, and the row block a wave waits for (a smaller
+    // item number) is held by a block that has started.
+    uint32_t first_item = blockIdx.x * kWavesPerBlock;
+    if (L.rows_per_block) {
+        __shared__ uint32_t block_ticket;
+        if (threadIdx.x == 0) block_ticket = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        first_item = __builtin_amdgcn_readfirstlane(block_ticket) * kWavesPerBlock;
     }
+    const uint32_t item = first_item + wave;         // wave-uniform
+    if (item < L.nitems) run_item(item);
 
     // What is still staged goes out with ONE returning atomic per block, not per wave: the single counter word
     // sustains ~90 returning atomics per microsecond chip-wide.
