@@ -657,7 +657,14 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
             uint32_t spins = 0;
             while (__hip_atomic_load(block_flags + tile_in_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < block) {
                 __builtin_amdgcn_s_sleep(32);
-                if (++spins == kHandoffSpins) {
+                ++spins;
+                if ((spins & 63u) == 0) {
+                    // the block before may never come: the run was aborted (its wave left without a hand-off), or a
+                    // wave somewhere gave up waiting
+                    if (abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
+                    if (__hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+                }
+                if (spins == kHandoffSpins) {
                     if (lane8 == 0) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     return false;
                 }
