@@ -357,11 +357,12 @@ __device__ __forceinline__ void expand_all(uint32_t (&C)[32], const LazySymbols&
 // plain C++, hipcc folds the chain into ONE dynamically indexed access, for which the 16 score registers (and the 32
 // window registers) have to live in consecutive VGPRs -- it then spills them as whole tuples inside the hot loop.
 template <int Q, int I>
-__device__ __forceinline__ void window_inputs(uint32_t l, const uint32_t (&cur)[kRegs], const uint32_t (&C)[32],
-                                              uint32_t& s, uint32_t& entry0, uint32_t& entry1) {
-    asm volatile("v_readlane_b32 %0, %3, %6\n\tv_readlane_b32 %1, %4, %6\n\tv_readlane_b32 %2, %5, %6"
-                 : "=&s"(s), "=&s"(entry0), "=&s"(entry1)
-                 : "v"(cur[I]), "v"(C[2 * Q + I]), "v"(C[2 * Q + 1 + I]), "s"(l));
+__device__ __forceinline__ void window_inputs(uint32_t l, const uint32_t (&cur)[kRegs], const uint32_t (&nxt)[kRegs],
+                                              const uint32_t (&C)[32], uint32_t& s, uint32_t& now, uint32_t& entry0,
+                                              uint32_t& entry1) {
+    asm volatile("v_readlane_b32 %0, %4, %8\n\tv_readlane_b32 %1, %5, %8\n\tv_readlane_b32 %2, %6, %8\n\tv_readlane_b32 %3, %7, %8"
+                 : "=&s"(s), "=&s"(now), "=&s"(entry0), "=&s"(entry1)
+                 : "v"(cur[I]), "v"(nxt[I]), "v"(C[2 * Q + I]), "v"(C[2 * Q + 1 + I]), "s"(l));
 }
 
 // The marked registers of lane l as a 16-bit mask.  Per register: read the lane, AND with the mark bits (SCC = any
@@ -469,8 +470,8 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
         do {
             const uint32_t r = (uint32_t)__builtin_ctz(regs);
             regs &= regs - 1;
-            uint32_t s = 0, entry0 = 0, entry1 = 0;
-            ((r == (uint32_t)I ? window_inputs<Q, I>(l, cur, C, s, entry0, entry1) : (void)0), ...);
+            uint32_t s = 0, now = 0, entry0 = 0, entry1 = 0;      // scores at the window's start and now, table entries
+            ((r == (uint32_t)I ? window_inputs<Q, I>(l, cur, nxt, C, s, now, entry0, entry1) : (void)0), ...);
             // the match words again, from the lane's table entries (uniform addresses: every lane reads the same)
             uint32_t w[kWindowSteps] = {0, 0, 0, 0};
             const u32x2 wa = match_words<2 * Q>(entry0);
@@ -483,21 +484,32 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
             }
             const uint32_t t0 = step0 + kWindowSteps * Q;
             const int64_t column0 = wave_diag0 + (int64_t)(32 * l + 2 * r) + (int64_t)t0;
+            // Only a cell that shows a mark crossed in these steps (a mark outlives them: that is what `safe` and the
+            // middle test are for); the other cell of the register is exact as it stands.
             int32_t low = (int32_t)(s << 16), high = (int32_t)(s & 0xffff0000u);     // the register's two cells
+            if (now & 1u) {
 #pragma unroll
-            for (int k = 0; k < NSTEPS; k++) {
-                low = scalar_sat_add(low, (int32_t)(w[k] << 16));
-                high = scalar_sat_add(high, (int32_t)(w[k] & 0xffff0000u));
-                if (low == INT32_MAX) {           // the low cell crossed at (row t0 + k, column column0 + k)
-                    if (k >= report_from) staged = emit_cell(sink, staged, t0 + k, column0 + k);
-                    low = INT32_MIN;
+                for (int k = 0; k < NSTEPS; k++) {
+                    low = scalar_sat_add(low, (int32_t)(w[k] << 16));
+                    if (low == INT32_MAX) {           // crossed at (row t0 + k, column column0 + k)
+                        if (k >= report_from) staged = emit_cell(sink, staged, t0 + k, column0 + k);
+                        low = INT32_MIN;
+                    }
                 }
-                if (high == INT32_MAX) {          // the high cell: one row behind, the same column
-                    if (k >= report_from) staged = emit_cell(sink, staged, t0 + k - 1, column0 + k);
-                    high = INT32_MIN;
-                }
+                now = (now & 0xffff0000u) | ((uint32_t)low >> 16);
             }
-            s = ((uint32_t)low >> 16) | ((uint32_t)high & 0xffff0000u);
+            if (now & 0x10000u) {
+#pragma unroll
+                for (int k = 0; k < NSTEPS; k++) {
+                    high = scalar_sat_add(high, (int32_t)(w[k] & 0xffff0000u));
+                    if (high == INT32_MAX) {          // the high cell: one row behind, the same column
+                        if (k >= report_from) staged = emit_cell(sink, staged, t0 + k - 1, column0 + k);
+                        high = INT32_MIN;
+                    }
+                }
+                now = (now & 0xffffu) | ((uint32_t)high & 0xffff0000u);
+            }
+            s = now;
             write_score_lane(nxt, s, l, r);
         } while (regs);
     } while (lanes);
@@ -550,6 +562,30 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
     for (int i = 0; i < kRegs; i++) any |= nxt[i];
     if (__builtin_expect(__any((any & kCrossedBits) != 0), 0))
         window_slow<Q, kWindowSteps>(cur, nxt, C, any, safe ? 0 : 2, sink, staged, step0, wave_diag0, regs);
+}
+
+// ONE step with the tables of step pair 0 (the step behind the model's last chunk: the high cells run one row behind
+// and still owe the last row; the low cells add a padding row, which scores 0).
+template <int... I>
+__device__ __forceinline__ void step_last(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
+                                          const HitSink& sink, uint32_t& staged, uint32_t step0, int64_t wave_diag0,
+                                          std::integer_sequence<int, I...> regs) {
+    constexpr int H = kRegs / 2;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        u32x2 m[H];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < H; i++) m[i] = match_words<0>(C[h * H + i]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(nxt[h * H + i]) : "v"(cur[h * H + i]), "v"(m[i].x));
+    }
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < kRegs; i++) any |= nxt[i];
+    if (__builtin_expect(__any((any & kCrossedBits) != 0), 0))
+        window_slow<0, 1>(cur, nxt, C, any, 0, sink, staged, step0, wave_diag0, regs);
 }
 
 // windows 0 .. N-1 of a chunk; the scores are in `a` on entry and, N being even, in `a` again on exit
@@ -750,13 +786,11 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
         }
         if (!go_on) return false;
         if (p_end == (int64_t)L.nrows_padded) {
-            // the high cells run one row behind: one more step gives them the model's last row (the window's other
-            // three steps add padding rows, which score 0)
+            // the high cells run one row behind: one more step gives them the model's last row
             build_tables(next_rows);                               // fetched for p_end by the last chunk
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-            expand_for_window<0>(C, z);
-            step_window<0>(x, x2, C, true, sink, staged, (uint32_t)p_end, d0, std::make_integer_sequence<int, kRegs>{});
+            step_last(x, x2, C, sink, staged, (uint32_t)p_end, d0, std::make_integer_sequence<int, kRegs>{});
         } else if (p_end < p_hi) {
             // the tile goes on in the next row block: hand the scores over (release: the stores, then the count)
 #pragma unroll
