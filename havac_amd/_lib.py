@@ -31,6 +31,9 @@ SIGNATURES = {
     "havac_dev_write_separator_mask": (C.c_int, [_vp, _u8p, C.c_uint64]),
     "havac_dev_write_sequence_chars": (C.c_int, [_vp, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
     "havac_dev_read_sequence": (C.c_int, [_vp, C.c_void_p, C.c_uint64]),
+    "havac_dev_read_separator_mask": (C.c_int, [_vp, C.c_void_p, C.c_uint64]),
+    "havac_dev_write_sequence_records": (C.c_int, [_vp, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "havac_dev_append_reverse_strand": (C.c_int, [_vp, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     "havac_dev_run_async": (C.c_int, [_vp]),
     "havac_dev_state": (C.c_int, [_vp]),
     "havac_dev_wait": (C.c_int, [_vp, C.c_uint32]),

@@ -633,6 +633,151 @@ extern "C" int havac_dev_read_sequence(havac_dev* d, uint8_t* out, uint64_t nbyt
     return HAVAC_OK;
 }
 
+extern "C" int havac_dev_read_separator_mask(havac_dev* d, uint8_t* out, uint64_t nbytes) {
+    if (!d || (!out && nbytes)) return HAVAC_E_ARGUMENT;
+    if (nbytes > d->mask_bytes) { d->err = "the device holds fewer separator-bitmap bytes than requested"; return HAVAC_E_LENGTH; }
+    if (nbytes == 0) return HAVAC_OK;
+    DevicePart& p = d->parts[0];
+    HIP_TRY(d->err, hipSetDevice(p.device));
+    HIP_TRY(d->err, hipMemcpy(out, p.d_mask, nbytes, hipMemcpyDeviceToHost));
+    return HAVAC_OK;
+}
+
+namespace {
+// host array -> a device array that lives until the caller frees it
+template <typename T>
+int to_device(std::string& err, const T* src, size_t n, T** out, hipStream_t stream) {
+    *out = nullptr;
+    if (n == 0) return HAVAC_OK;
+    HIP_TRY(err, hipMalloc(out, n * sizeof(T)));
+    hipError_t e = hipMemcpyAsync(*out, src, n * sizeof(T), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) { (void)hipFree(*out); *out = nullptr; err = hip_msg("hipMemcpyAsync", e); return HAVAC_E_RUNTIME; }
+    return HAVAC_OK;
+}
+}  // namespace
+
+extern "C" int havac_dev_write_sequence_records(havac_dev* d, const char* chars, uint64_t nchars, const uint64_t* record_ends,
+                                                uint32_t nrecords, uint64_t* record_starts_out) {
+    if (!d || (!chars && nchars) || (nrecords && !record_ends)) return HAVAC_E_ARGUMENT;
+    // the layout: record k occupies [start_k, start_k + len_k), then padding to an even column, then 2 separator columns
+    std::vector<uint64_t> starts(nrecords), begins(nrecords), lens(nrecords);
+    uint64_t at = 0;
+    for (uint32_t k = 0; k < nrecords; k++) {
+        const uint64_t begin = k ? record_ends[k - 1] : 0;
+        if (record_ends[k] < begin || record_ends[k] > nchars) { d->err = "record ends must be ascending and inside the text"; return HAVAC_E_ARGUMENT; }
+        starts[k] = at; begins[k] = begin; lens[k] = record_ends[k] - begin;
+        at += lens[k];
+        at += at & 1;
+        at += 2;
+    }
+    if (record_starts_out) std::copy(starts.begin(), starts.end(), record_starts_out);
+    const uint64_t ncolumns = (at + HAVAC_SEGMENT_COLUMNS - 1) / HAVAC_SEGMENT_COLUMNS * HAVAC_SEGMENT_COLUMNS;
+    const uint64_t nbytes = ncolumns / 4;
+    if (nbytes >= (4ull << 30)) {
+        d->err = "compressed sequence size must be less than 4GiB. length requested: " + std::to_string(nbytes) + " bytes.";
+        return HAVAC_E_LENGTH;
+    }
+    d->seq_bytes = nbytes;
+    d->mask_bytes = 0;
+    if (nbytes == 0) return HAVAC_OK;
+    const bool locked = nchars && hipHostRegister(const_cast<char*>(chars), nchars, hipHostRegisterDefault) == hipSuccess;
+    if (!locked) (void)hipGetLastError();
+    auto run = [&]() -> int {
+        for (DevicePart& p : d->parts) {
+            HIP_TRY(d->err, hipSetDevice(p.device));
+            if (p.seq_alloc < nbytes) {
+                if (p.d_seq) (void)hipFree(p.d_seq);
+                p.d_seq = nullptr; p.seq_alloc = 0;
+                HIP_TRY(d->err, hipMalloc(&p.d_seq, nbytes));
+                p.seq_alloc = nbytes;
+            }
+            if (p.mask_alloc < nbytes / 4) {
+                if (p.d_mask) (void)hipFree(p.d_mask);
+                p.d_mask = nullptr; p.mask_alloc = 0;
+                HIP_TRY(d->err, hipMalloc(&p.d_mask, nbytes / 4));
+                p.mask_alloc = nbytes / 4;
+            }
+            uint8_t* d_text = nullptr;
+            uint64_t *d_starts = nullptr, *d_begins = nullptr, *d_lens = nullptr;
+            auto release = [&]() { (void)hipFree(d_text); (void)hipFree(d_starts); (void)hipFree(d_begins); (void)hipFree(d_lens); };
+            int rc = to_device(d->err, reinterpret_cast<const uint8_t*>(chars), (size_t)nchars, &d_text, p.stream);
+            if (rc == HAVAC_OK) rc = to_device(d->err, starts.data(), starts.size(), &d_starts, p.stream);
+            if (rc == HAVAC_OK) rc = to_device(d->err, begins.data(), begins.size(), &d_begins, p.stream);
+            if (rc == HAVAC_OK) rc = to_device(d->err, lens.data(), lens.size(), &d_lens, p.stream);
+            if (rc != HAVAC_OK) { release(); return rc; }
+            const uint64_t words = ncolumns / 16;
+            hipLaunchKernelGGL(ssv_pack_records, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, p.stream,
+                               d_text, d_starts, d_begins, d_lens, nrecords, at, ncolumns,
+                               reinterpret_cast<uint32_t*>(p.d_seq), p.d_mask);
+            hipError_t e = hipStreamSynchronize(p.stream);
+            if (e == hipSuccess) e = hipGetLastError();
+            release();
+            if (e != hipSuccess) { d->err = hip_msg("packing the records", e); return HAVAC_E_RUNTIME; }
+        }
+        return HAVAC_OK;
+    };
+    const int rc = run();
+    if (locked) (void)hipHostUnregister(const_cast<char*>(chars));
+    if (rc == HAVAC_OK) d->mask_bytes = nbytes / 4;
+    return rc;
+}
+
+extern "C" int havac_dev_append_reverse_strand(havac_dev* d, const uint64_t* starts, const uint64_t* residues, uint32_t nrecords,
+                                               uint64_t* forward_columns_out) {
+    if (!d || (nrecords && (!starts || !residues))) return HAVAC_E_ARGUMENT;
+    if (d->seq_bytes == 0) { d->err = "no sequence on the device to append a second strand to"; return HAVAC_E_LOGIC; }
+    if (d->has_run && !d->finished) { d->err = "cannot change the sequence during a run"; return HAVAC_E_LOGIC; }
+    const uint64_t fbytes = d->seq_bytes, nf = fbytes * 4;
+    if (2 * fbytes >= (4ull << 30)) {
+        d->err = "compressed sequence size must be less than 4GiB. length requested: " + std::to_string(2 * fbytes) + " bytes.";
+        return HAVAC_E_LENGTH;
+    }
+    for (uint32_t k = 0; k < nrecords; k++)
+        if (starts[k] + residues[k] > nf || (k && starts[k] < starts[k - 1] + residues[k - 1])) {
+            d->err = "records must be ascending, disjoint and inside the forward sequence";
+            return HAVAC_E_ARGUMENT;
+        }
+    for (DevicePart& p : d->parts) {
+        HIP_TRY(d->err, hipSetDevice(p.device));
+        if (p.seq_alloc < 2 * fbytes) {          // grow, keeping the forward half
+            uint8_t* bigger = nullptr;
+            HIP_TRY(d->err, hipMalloc(&bigger, 2 * fbytes));
+            hipError_t e = hipMemcpyAsync(bigger, p.d_seq, fbytes, hipMemcpyDeviceToDevice, p.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(p.stream);
+            if (e != hipSuccess) { (void)hipFree(bigger); d->err = hip_msg("growing the sequence buffer", e); return HAVAC_E_RUNTIME; }
+            (void)hipFree(p.d_seq);
+            p.d_seq = bigger; p.seq_alloc = 2 * fbytes;
+        }
+        uint64_t *d_starts = nullptr, *d_residues = nullptr;
+        int rc = to_device(d->err, starts, nrecords, &d_starts, p.stream);
+        if (rc == HAVAC_OK) rc = to_device(d->err, residues, nrecords, &d_residues, p.stream);
+        if (rc != HAVAC_OK) { (void)hipFree(d_starts); (void)hipFree(d_residues); return rc; }
+        const uint64_t words = nf / 16;
+        hipLaunchKernelGGL(ssv_reverse_strand, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, p.stream,
+                           reinterpret_cast<uint32_t*>(p.d_seq), nf, d_starts, d_residues, nrecords);
+        hipError_t e = hipSuccess;
+        if (d->mask_bytes) {                        // the second half has the separators of the first
+            if (p.mask_alloc < 2 * d->mask_bytes) {
+                uint8_t* bigger = nullptr;
+                e = hipMalloc(&bigger, 2 * d->mask_bytes);
+                if (e == hipSuccess) e = hipMemcpyAsync(bigger, p.d_mask, d->mask_bytes, hipMemcpyDeviceToDevice, p.stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(p.stream);
+                if (e == hipSuccess) { (void)hipFree(p.d_mask); p.d_mask = bigger; p.mask_alloc = 2 * d->mask_bytes; }
+                else if (bigger) (void)hipFree(bigger);
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(p.d_mask + d->mask_bytes, p.d_mask, d->mask_bytes, hipMemcpyDeviceToDevice, p.stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(p.stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        (void)hipFree(d_starts); (void)hipFree(d_residues);
+        if (e != hipSuccess) { d->err = hip_msg("appending the second strand", e); return HAVAC_E_RUNTIME; }
+    }
+    d->seq_bytes = 2 * fbytes;
+    d->mask_bytes *= 2;
+    if (forward_columns_out) *forward_columns_out = nf;
+    return HAVAC_OK;
+}
+
 extern "C" int havac_dev_write_separator_mask(havac_dev* d, const uint8_t* pair_bitmap, uint64_t nbytes) {
     if (!d || (!pair_bitmap && nbytes)) return HAVAC_E_ARGUMENT;
     if (nbytes == 0) { d->mask_bytes = 0; return HAVAC_OK; }

@@ -79,14 +79,35 @@ void Havac::loadSequence(const std::string fastaSrc) {
     if (rc == FASTA_VECTOR_ALLOCATION_FAIL) throw std::bad_alloc();
     if (rc == FASTA_VECTOR_FILE_OPEN_FAIL) throw std::runtime_error("Could not open fasta file for reading.");
     if (rc == FASTA_VECTOR_FILE_READ_FAIL) throw std::runtime_error("Error while reading from the opened fasta file.");
-    if (devicePacking_ && !boundaryMode_ && !bothStrands_) {
-        // the text goes to the GPU in chunks and is packed there; the host only looks for the
-        // characters that are not a/c/g/t and draws their symbols (same rand() order as SequencePreprocessor)
-        vector<uint64_t> patchColumns;
-        vector<uint8_t> patchSymbols;
-        SequencePreprocessor::collectPatches(fastaVector, patchColumns, patchSymbols);
-        check(havac_dev_write_sequence_chars(dev_, fastaVector->sequence.charData, fastaVector->sequence.count,
-                                             patchColumns.data(), patchSymbols.data(), patchColumns.size()));
+    if (devicePacking_) {
+        // the text goes to the GPU and every layout is made there.
+        vector<uint64_t> ends, starts, residues;
+        for (size_t j = 0; j < fastaVector->metadata.count; j++) ends.push_back(fastaVector->metadata.data[j].sequenceEndPosition);
+        if (boundaryMode_) {
+            // every record its own columns + a separator pair, a/c/g as they are, everything else T (no rand())
+            recordStarts_.assign(ends.size(), 0);
+            check(havac_dev_write_sequence_records(dev_, fastaVector->sequence.charData, fastaVector->sequence.count, ends.data(),
+                                                   (uint32_t)ends.size(), recordStarts_.data()));
+            recordLengths_.clear();
+            for (size_t j = 0; j < ends.size(); j++) recordLengths_.push_back(ends[j] - (j ? ends[j - 1] : 0));
+        } else {
+            // the reference's layout: the host only looks for the characters that are not a/c/g/t and draws their
+            // symbols (same rand() order as SequencePreprocessor); chunks are packed while later ones cross PCIe
+            vector<uint64_t> patchColumns;
+            vector<uint8_t> patchSymbols;
+            SequencePreprocessor::collectPatches(fastaVector, patchColumns, patchSymbols);
+            check(havac_dev_write_sequence_chars(dev_, fastaVector->sequence.charData, fastaVector->sequence.count,
+                                                 patchColumns.data(), patchSymbols.data(), patchColumns.size()));
+        }
+        if (bothStrands_) {
+            for (size_t j = 0; j < ends.size(); j++) {
+                const uint64_t begin = j ? ends[j - 1] : 0;
+                starts.push_back(boundaryMode_ ? recordStarts_[j] : begin);
+                residues.push_back(ends[j] - begin - 1);
+            }
+            check(havac_dev_append_reverse_strand(dev_, starts.data(), residues.data(), (uint32_t)starts.size(), &forwardColumns_));
+            residueCounts_ = residues;
+        }
         sequenceLoadedToDevice = true;
         return;
     }

@@ -96,9 +96,10 @@ public:
     void setBothStrands(bool on);
     // Hits of the finished run merged into windows (see HavacWindow); `flank` residues are added on both sides.
     vector<HavacWindow> getWindowsFromFinishedRun(uint32_t flank = 0);
-    // Packing on the GPU, on by default in the plain mode: loadSequence sends the text
-    // and the symbols it drew for the non-a/c/g/t columns; the device buffer is byte for byte what the host packer
-    // (SequencePreprocessor) would have produced with the same rand() state.  Off = pack on the host.
+    // Packing on the GPU, on by default: loadSequence sends the text (and, in the plain
+    // mode, the symbols it drew for the non-a/c/g/t columns); the boundary-mode layout and the second strand are made
+    // on the GPU as well.  The device buffers are byte for byte what the host packer (SequencePreprocessor) would have
+    // produced with the same rand() state.  Off = pack on the host.
     void setDevicePacking(bool on);
     void setHitCapacity(uint64_t maxHits);                 // the reference's buffer is a fixed 3.5 GiB
     void lastRunMilliseconds(float *ssvKernelMs, float *totalMs);

@@ -181,6 +181,36 @@ int havac_host_pack_fasta(const char *path, int64_t seed, uint8_t *out, uint64_t
     return HAVAC_OK;
 }
 
+int havac_host_pack_fasta_layout(const char *path, int64_t seed, int boundaryMode, int bothStrands, uint8_t *out, uint64_t cap,
+                                 uint64_t *nbytes, uint8_t *maskOut, uint64_t maskCap, uint64_t *maskBytes,
+                                 uint64_t *forwardColumns) {
+    FastaVector fv;
+    if (fastaVectorInit(&fv) != FASTA_VECTOR_OK) return HAVAC_E_NOMEM;
+    FastaVectorReturnCode rc = fastaVectorReadFasta(path, &fv);
+    if (rc != FASTA_VECTOR_OK) { fastaVectorDealloc(&fv); return rc == FASTA_VECTOR_ALLOCATION_FAIL ? HAVAC_E_NOMEM : HAVAC_E_RUNTIME; }
+    if (seed >= 0) std::srand((unsigned)seed);
+    SequencePreprocessor pre(&fv, boundaryMode != 0);
+    uint64_t nf = 0;
+    if (bothStrands) {
+        vector<uint64_t> starts, residues;
+        for (size_t j = 0; j < fv.metadata.count; j++) {
+            const uint64_t begin = j ? fv.metadata.data[j - 1].sequenceEndPosition : 0;
+            starts.push_back(boundaryMode ? pre.getRecordStarts()[j] : begin);
+            residues.push_back(fv.metadata.data[j].sequenceEndPosition - begin - 1);
+        }
+        nf = pre.appendReverseStrand(starts, residues);
+    }
+    vector<uint8_t> &packed = pre.getCompressedSequenceBuffer();
+    vector<uint8_t> &mask = pre.getSeparatorMask();
+    if (nbytes) *nbytes = packed.size();
+    if (maskBytes) *maskBytes = mask.size();
+    if (forwardColumns) *forwardColumns = nf;
+    if (out && cap >= packed.size()) std::memcpy(out, packed.data(), packed.size());
+    if (maskOut && maskCap >= mask.size() && !mask.empty()) std::memcpy(maskOut, mask.data(), mask.size());
+    fastaVectorDealloc(&fv);
+    return HAVAC_OK;
+}
+
 int havac_host_text_and_patches(const char *path, int64_t seed, char *chars, uint64_t charsCap, uint64_t *nchars,
                                 uint64_t *patchColumns, uint8_t *patchSymbols, uint64_t patchCap, uint64_t *npatches) {
     FastaVector fv;

@@ -202,6 +202,73 @@ __global__ void ssv_patch_symbols(const uint64_t* __restrict__ columns, const ui
 }
 
 // ---------------------------------------------------------------------------
+// Boundary-mode layout on the GPU (SURVEY.md section 8 rows f2 + f4; host counterpart: SequencePreprocessor(fasta, true)).
+// Record j keeps its own columns [out_start[j], out_start[j] + len[j]) -- residues and terminator column, from
+// chars[src_begin[j] ..] -- followed, at the next even column, by one separator pair; a/c/g are 0/1/2, every other
+// character is T (host/test/Ssv.cpp:29-34), no rand().  One thread makes one 32-bit word (16 columns) and the byte of
+// the separator bitmap that belongs to it (one bit per aligned symbol pair); columns outside every record are symbol 0,
+// and every pair from `layout_end` on (the padding behind the last record) is masked.
+__global__ void ssv_pack_records(const uint8_t* __restrict__ chars, const uint64_t* __restrict__ out_start,
+                                 const uint64_t* __restrict__ src_begin, const uint64_t* __restrict__ len, uint32_t nrecords,
+                                 uint64_t layout_end, uint64_t ncolumns, uint32_t* __restrict__ packed, uint8_t* __restrict__ mask) {
+    const uint64_t word = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t col0 = word * 16;
+    if (col0 >= ncolumns) return;
+    // the last record that starts at or before col0 (none: the word lies before the first record, which starts at 0)
+    uint32_t lo = 0, hi = nrecords;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (out_start[mid] <= col0) lo = mid + 1; else hi = mid;
+    }
+    uint32_t j = lo ? lo - 1 : 0;
+    uint32_t out = 0, bits = 0;
+    for (int i = 0; i < 16; i++) {
+        const uint64_t col = col0 + i;
+        while (j + 1 < nrecords && out_start[j + 1] <= col) j++;
+        if (nrecords && col >= out_start[j]) {
+            const uint64_t off = col - out_start[j];
+            if (off < len[j]) {
+                const uint32_t ch = chars[src_begin[j] + off] | 0x20u;
+                const uint32_t code = ch == 'a' ? 0u : ch == 'c' ? 1u : ch == 'g' ? 2u : 3u;
+                out |= code << (2 * i);
+            }
+            const uint64_t behind = out_start[j] + len[j];
+            if ((i & 1) == 0 && col == behind + (behind & 1)) bits |= 1u << (i / 2);      // the record's separator pair
+        }
+        if ((i & 1) == 0 && col >= layout_end) bits |= 1u << (i / 2);
+    }
+    packed[word] = out;
+    mask[word] = (uint8_t)bits;
+}
+
+// Second strand on the GPU (row f3; host counterpart: SequencePreprocessor::appendReverseStrand): columns [nf, 2 nf)
+// repeat [0, nf) with every record's residues reverse-complemented in place (3 - symbol, order reversed); terminator,
+// separator and padding columns are copied.  starts[] ascending.  Reads the first half, writes the second.
+__global__ void ssv_reverse_strand(uint32_t* __restrict__ packed, uint64_t nf, const uint64_t* __restrict__ starts,
+                                   const uint64_t* __restrict__ residues, uint32_t nrecords) {
+    const uint64_t word = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t col0 = word * 16;
+    if (col0 >= nf) return;
+    auto symbol = [&](uint64_t col) -> uint32_t { return (packed[col / 16] >> (2 * (col % 16))) & 3u; };
+    uint32_t lo = 0, hi = nrecords;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (starts[mid] <= col0) lo = mid + 1; else hi = mid;
+    }
+    uint32_t j = lo ? lo - 1 : 0;
+    uint32_t out = 0;
+    for (int i = 0; i < 16; i++) {
+        const uint64_t col = col0 + i;
+        while (j + 1 < nrecords && starts[j + 1] <= col) j++;
+        uint32_t code = symbol(col);
+        if (nrecords && col >= starts[j] && col - starts[j] < residues[j])
+            code = 3u - symbol(starts[j] + residues[j] - 1 - (col - starts[j]));
+        out |= code << (2 * i);
+    }
+    packed[(nf + col0) / 16] = out;
+}
+
+// ---------------------------------------------------------------------------
 typedef short short2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) u32x2* lds_words_t;

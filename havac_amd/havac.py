@@ -44,6 +44,8 @@ HOST_SIGNATURES = {
     "havac_host_last_error": (C.c_char_p, [_vp]),
     "havac_host_pack_fasta": (C.c_int, [C.c_char_p, C.c_int64, _vp, C.c_uint64, C.POINTER(C.c_uint64),
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "havac_host_pack_fasta_layout": (C.c_int, [C.c_char_p, C.c_int64, C.c_int, C.c_int, _vp, C.c_uint64, C.POINTER(C.c_uint64),
+                                               _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "havac_host_project_hmm": (C.c_int, [C.c_char_p, C.c_float, _vp, C.c_uint64, C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint32), _vp, C.c_uint32]),
     "havac_host_scaling_factor": (C.c_float, [C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_float]),
@@ -242,6 +244,24 @@ def text_and_patches(path: str, seed: int = -1):
     if rc != 0:
         raise_for(rc, f"could not read {path}")
     return chars, cols, syms
+
+
+def pack_fasta_layout(path: str, boundary_mode: bool, both_strands: bool, seed: int = -1):
+    """The host packer's other layouts -> (packed bytes, separator bitmap bytes (empty without boundary mode),
+    forward columns (0 without both strands))."""
+    L = load_host()
+    nb, mb, nf = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    rc = L.havac_host_pack_fasta_layout(os.fsencode(path), seed, int(boundary_mode), int(both_strands), None, 0, C.byref(nb),
+                                        None, 0, C.byref(mb), C.byref(nf))
+    if rc != 0:
+        raise_for(rc, f"could not read {path}")
+    packed, mask = np.empty(nb.value, np.uint8), np.empty(mb.value, np.uint8)
+    rc = L.havac_host_pack_fasta_layout(os.fsencode(path), seed, int(boundary_mode), int(both_strands),
+                                        packed.ctypes.data if packed.size else None, packed.size, C.byref(nb),
+                                        mask.ctypes.data if mask.size else None, mask.size, C.byref(mb), C.byref(nf))
+    if rc != 0:
+        raise_for(rc, f"could not read {path}")
+    return packed, mask, nf.value
 
 
 def project_hmm(path: str, p_value: float = 0.02):

@@ -105,6 +105,32 @@ class HavacHwClient:
         self._check(self._L.havac_dev_read_sequence(self._h, out.ctypes.data if out.size else None, out.size))
         return out
 
+    def writeSequenceRecords(self, chars, recordEnds):
+        """Not in the reference (rows f2 + f4): the boundary-mode layout made on the GPU from the text; returns each
+        record's first column."""
+        buf = np.ascontiguousarray(np.frombuffer(chars, dtype=np.uint8) if isinstance(chars, (bytes, bytearray)) else chars,
+                                   dtype=np.uint8)
+        ends = np.ascontiguousarray(recordEnds, dtype=np.uint64)
+        starts = np.zeros(ends.size, np.uint64)
+        self._check(self._L.havac_dev_write_sequence_records(self._h, buf.ctypes.data if buf.size else None, buf.size,
+                                                             ends.ctypes.data if ends.size else None, ends.size,
+                                                             starts.ctypes.data if ends.size else None))
+        return starts
+
+    def appendReverseStrand(self, starts, residues) -> int:
+        """Not in the reference (row f3): doubles the sequence on the device; returns the forward half's columns."""
+        st = np.ascontiguousarray(starts, dtype=np.uint64)
+        rs = np.ascontiguousarray(residues, dtype=np.uint64)
+        nf = C.c_uint64(0)
+        self._check(self._L.havac_dev_append_reverse_strand(self._h, st.ctypes.data if st.size else None,
+                                                            rs.ctypes.data if rs.size else None, st.size, C.byref(nf)))
+        return nf.value
+
+    def readSeparatorMask(self, nbytes: int) -> np.ndarray:
+        out = np.empty(int(nbytes), np.uint8)
+        self._check(self._L.havac_dev_read_separator_mask(self._h, out.ctypes.data if out.size else None, out.size))
+        return out
+
     def writeSeparatorMask(self, pairBitmap):
         """Boundary mode (not in the reference): one bit per aligned symbol pair; None or empty removes the mask."""
         buf = np.ascontiguousarray(pairBitmap if pairBitmap is not None else [], dtype=np.uint8)

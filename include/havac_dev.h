@@ -116,8 +116,27 @@ int havac_dev_write_sequence(havac_dev *dev, const uint8_t *packed2bit, uint64_t
 int havac_dev_write_sequence_chars(havac_dev *dev, const char *chars, uint64_t nchars, const uint64_t *patch_columns,
                                    const uint8_t *patch_symbols, uint64_t npatches);
 
-/* The packed sequence as it stands in HBM (first GPU of the handle): for checking the entry point above. */
+/* The packed sequence as it stands in HBM (first GPU of the handle): for checking the entry points around it. */
 int havac_dev_read_sequence(havac_dev *dev, uint8_t *packed2bit, uint64_t nbytes);
+/* The separator bitmap as it stands in HBM (first GPU of the handle); nbytes <= sequence bytes / 4. */
+int havac_dev_read_separator_mask(havac_dev *dev, uint8_t *pair_bitmap, uint64_t nbytes);
+
+/* Optional, not in the reference (rows f2 + f4: the boundary-mode layout built on the GPU).  `chars` as for
+ * havac_dev_write_sequence_chars; record k is chars[record_ends[k-1] .. record_ends[k]) (its residues and the '\0'
+ * behind them; record_ends ascending, the last one == nchars).  Every record gets its own columns followed, at the
+ * next even column, by one separator pair; a/c/g are 0/1/2 and every other character is T (host/test/Ssv.cpp:29-34,
+ * no rand()); the sequence and its separator bitmap are both made on the GPU and equal, byte for byte, what the host
+ * layer's SequencePreprocessor(fasta, true) packs.  record_starts_out (nrecords entries, may be NULL) receives each
+ * record's first column. */
+int havac_dev_write_sequence_records(havac_dev *dev, const char *chars, uint64_t nchars, const uint64_t *record_ends,
+                                     uint32_t nrecords, uint64_t *record_starts_out);
+
+/* Optional, not in the reference (row f3: both strands, made on the GPU).  Doubles the sequence that is on the device
+ * (and its separator bitmap, if any): columns [Nf, 2 Nf) repeat [0, Nf) with the `residues[k]` columns from
+ * `starts[k]` on reverse-complemented in place for every record k (starts ascending); everything else is copied.
+ * *forward_columns_out = Nf.  Equals SequencePreprocessor::appendReverseStrand on the host-packed buffer. */
+int havac_dev_append_reverse_strand(havac_dev *dev, const uint64_t *starts, const uint64_t *residues, uint32_t nrecords,
+                                    uint64_t *forward_columns_out);
 
 /* Optional, not in the reference ("boundary mode").  One bit per aligned symbol
  * pair (bit k of byte j = symbols 16j+2k, 16j+2k+1) of the sequence written before it; a set bit makes both

@@ -76,6 +76,14 @@ int havac_host_resolve_hits(const char *fasta_path, const char *hmm_path, const 
                             uint64_t *sequence_position, uint32_t *sequence_index, uint32_t *phmm_position,
                             uint32_t *phmm_index, uint32_t cap, uint32_t *count);
 
+/* The host packer in its other layouts (checking aid for the GPU-built ones): boundary mode (SequencePreprocessor(fasta,
+ * true): packed sequence + separator bitmap) and/or both strands (appendReverseStrand).  Writes at most `cap` / `mask_cap`
+ * bytes; *nbytes / *mask_nbytes = the full sizes (mask 0 without boundary mode); *forward_columns = the forward half's
+ * columns (0 without both strands). */
+int havac_host_pack_fasta_layout(const char *fasta_path, int64_t seed, int boundary_mode, int both_strands, uint8_t *out,
+                                 uint64_t cap, uint64_t *nbytes, uint8_t *mask_out, uint64_t mask_cap, uint64_t *mask_nbytes,
+                                 uint64_t *forward_columns);
+
 /* What loadSequence sends to the GPU when it packs there: the file's characters (records + terminators; nchars) and
  * the columns that are not a/c/g/t with the symbols drawn for them (SequencePreprocessor::collectPatches); seed as
  * in havac_host_pack_fasta.  Writes at most `cap` characters / patches; *nchars, *npatches = the full counts. */

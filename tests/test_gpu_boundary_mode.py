@@ -193,6 +193,41 @@ def test_boundary_mode_with_both_strands(tmp_path, oracle):
     assert got == want
 
 
+@pytest.mark.parametrize("boundary,strands", [(True, False), (False, True), (True, True)])
+def test_layouts_made_on_the_gpu_equal_the_host_packer(tmp_path, boundary, strands):
+    """Rows f2 + f3 + f4: the boundary-mode layout (every record its own columns + a separator pair, bitmap included)
+    and the second strand are built on the GPU from the text (havac_dev_write_sequence_records,
+    havac_dev_append_reverse_strand); read back, sequence and bitmap equal the host packer's byte for byte.  Ragged
+    records: odd and even lengths, an empty one, ambiguity codes, one shorter than a word."""
+    import ctypes as C
+    from havac_amd import havac
+    from havac_amd.hw_client import HavacHwClient
+    rng = np.random.default_rng(5)
+    alphabet = np.frombuffer(b"ACGTacgtNRYKMSWn", np.uint8)
+    lengths = [4001, 0, 17, 30000, 7, 12288, 2]
+    records = [(f"r{k}", bytes(alphabet[rng.integers(0, alphabet.size, size=n)]).decode()) for k, n in enumerate(lengths)]
+    fa = str(tmp_path / "ragged.fa")
+    synth.write_fasta(fa, records)
+    seed = 77
+    want_seq, want_mask, want_nf = havac.pack_fasta_layout(fa, boundary, strands, seed=seed)
+    chars, cols, syms = havac.text_and_patches(fa, seed=seed)                # the same rand() draws as the host packer
+    ends = np.cumsum([n + 1 for n in lengths]).astype(np.uint64)            # every record: its residues + the terminator
+    c = HavacHwClient()
+    if boundary:
+        starts = c.writeSequenceRecords(chars, ends)
+    else:
+        c.writeSequenceChars(chars, cols, syms)
+        starts = np.concatenate([[0], ends[:-1]]).astype(np.uint64)
+    if strands:
+        nf = c.appendReverseStrand(starts, np.asarray(lengths, np.uint64))
+        assert nf == want_nf
+    got_seq = c.readSequence(want_seq.size)
+    assert np.array_equal(got_seq, want_seq)
+    if boundary:
+        assert np.array_equal(c.readSeparatorMask(want_mask.size), want_mask)
+    c.close()
+
+
 def test_windows_of_a_run_cover_the_planted_homologs(tmp_path, oracle):
     """f3, second half: Havac::getWindowsFromFinishedRun on both strands = the host merge applied to the run's own
     hit list, and every hit lies inside a window of its own record, model and strand."""
