@@ -49,7 +49,7 @@
 //  * HITS are rare (about 1e-5 per cell on Dfam-like models): after each window
 //    the 16 score registers are OR-ed and one wave-wide test looks at the low
 //    bytes; only then the slow path runs, one marked lane and register at a
-//    time and on the SCALAR unit: the register's four steps are taken again
+//    time (found by halving) and on the SCALAR unit: the register's four steps are taken again
 //    from the scores the window started with (kept in the other register set),
 //    crossings are reported and put back to score 0 on the way (0x7fff + 1 =
 //    0x8000; test/softSsv/SoftSsv.cpp:43-44), and the exact result is written
@@ -432,34 +432,6 @@ __device__ __forceinline__ void window_inputs(uint32_t l, const uint32_t (&cur)[
                  : "v"(cur[I]), "v"(nxt[I]), "v"(C[2 * Q + I]), "v"(C[2 * Q + 1 + I]), "s"(l));
 }
 
-// The marked registers of lane l as a 16-bit mask.  Per register: read the lane, AND with the mark bits (SCC = any
-// set), select the register's bit on SCC, OR it in -- four instructions; hipcc makes five of the same in C++.
-__device__ __forceinline__ uint32_t marked_registers(const uint32_t (&n)[kRegs], uint32_t l) {
-    static_assert(kRegs == 16, "the asm below names sixteen registers");
-    uint32_t mask = 0, t;
-    asm volatile("v_readlane_b32 %1, %3, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 1, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %4, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 2, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %5, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 4, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %6, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 8, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %7, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 16, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %8, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 32, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %9, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 64, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %10, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 128, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %11, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 256, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %12, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 512, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %13, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 1024, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %14, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 2048, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %15, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 4096, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %16, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 8192, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %17, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 16384, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 "v_readlane_b32 %1, %18, %2\n\ts_and_b32 %1, %1, 0x10001\n\ts_cselect_b32 %1, 32768, 0\n\ts_or_b32 %0, %0, %1\n\t"
-                 : "+s"(mask), "=&s"(t)
-                 : "s"(l), "v"(n[0]), "v"(n[1]), "v"(n[2]), "v"(n[3]), "v"(n[4]), "v"(n[5]), "v"(n[6]), "v"(n[7]),
-                   "v"(n[8]), "v"(n[9]), "v"(n[10]), "v"(n[11]), "v"(n[12]), "v"(n[13]), "v"(n[14]), "v"(n[15])
-                 : "scc");
-    return mask;
-}
-
 // Lane l of score register r (0..15, wave-uniform) := s.  ONE asm statement that names all 16 registers and branches
 // inside (a binary tree on r: four compares): written as sixteen conditional C++ statements, the merge of the sixteen paths makes hipcc treat the register
 // set as one 512-bit value that it copies and spills as a whole in the hot loop (1.2 KB of scratch).
@@ -519,6 +491,27 @@ __device__ __forceinline__ void write_score_lane(uint32_t (&n)[kRegs], uint32_t 
                  : "m0", "scc");
 }
 
+// ONE marked register of lane l among registers [Lo, Hi) (there is one): halve the range by OR-ing the lower half's
+// registers (two to four vector instructions on static registers) and looking at lane l of the result; at the leaf, the
+// values the replay needs of that register, read with static register names.  Four levels, ~25 instructions, where
+// reading the lane of all 16 registers took 64.
+template <int Q, int Lo, int Hi>
+__device__ __forceinline__ void find_marked(uint32_t l, const uint32_t (&cur)[kRegs], const uint32_t (&nxt)[kRegs],
+                                            const uint32_t (&C)[32], uint32_t& r, uint32_t& s, uint32_t& now,
+                                            uint32_t& entry0, uint32_t& entry1) {
+    if constexpr (Hi - Lo == 1) {
+        r = Lo;
+        window_inputs<Q, Lo>(l, cur, nxt, C, s, now, entry0, entry1);
+    } else {
+        constexpr int Mid = (Lo + Hi) / 2;
+        uint32_t lower = nxt[Lo];
+#pragma unroll
+        for (int i = Lo + 1; i < Mid; i++) lower |= nxt[i];
+        if (__builtin_amdgcn_readlane(lower, l) & kCrossedBits) find_marked<Q, Lo, Mid>(l, cur, nxt, C, r, s, now, entry0, entry1);
+        else find_marked<Q, Mid, Hi>(l, cur, nxt, C, r, s, now, entry0, entry1);
+    }
+}
+
 // `marked` (per lane) = OR of the score registers after NSTEPS (2 or 4) steps of window Q.  For every lane and register
 // that shows a mark: take the register's NSTEPS steps again on the scalar unit from `cur` (the scores the window started
 // from), report the crossings of steps >= report_from (an unsafe window has reported those of its first two steps at
@@ -529,16 +522,14 @@ template <int Q, int NSTEPS, int... I>
 __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
                                             uint32_t marked, int report_from, const HitSink& sink, uint32_t& staged,
                                             uint32_t step0, int64_t wave_diag0, std::integer_sequence<int, I...>) {
-    unsigned long long lanes = __ballot((marked & kCrossedBits) != 0);
     do {
-        const uint32_t l = (uint32_t)__builtin_ctzll(lanes);
-        lanes &= lanes - 1;
-        uint32_t regs = marked_registers(nxt, l);
+        unsigned long long lanes = __ballot((marked & kCrossedBits) != 0);
         do {
-            const uint32_t r = (uint32_t)__builtin_ctz(regs);
-            regs &= regs - 1;
-            uint32_t s = 0, now = 0, entry0 = 0, entry1 = 0;      // scores at the window's start and now, table entries
-            ((r == (uint32_t)I ? window_inputs<Q, I>(l, cur, nxt, C, s, now, entry0, entry1) : (void)0), ...);
+            const uint32_t l = (uint32_t)__builtin_ctzll(lanes);
+            lanes &= lanes - 1;
+            // one marked register of this lane (a second one, rare, is found by the look after the lanes)
+            uint32_t r = 0, s = 0, now = 0, entry0 = 0, entry1 = 0;      // register; scores at the window's start and now; table entries
+            find_marked<Q, 0, kRegs>(l, cur, nxt, C, r, s, now, entry0, entry1);
             // the match words again, from the lane's table entries (uniform addresses: every lane reads the same)
             uint32_t w[kWindowSteps] = {0, 0, 0, 0};
             const u32x2 wa = match_words<2 * Q>(entry0);
@@ -578,8 +569,11 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
             }
             s = now;
             write_score_lane(nxt, s, l, r);
-        } while (regs);
-    } while (lanes);
+        } while (lanes);
+        marked = 0;
+#pragma unroll
+        for (int i = 0; i < kRegs; i++) marked |= nxt[i];
+    } while (__any((marked & kCrossedBits) != 0));
 }
 
 // Steps 4Q .. 4Q+3 of the chunk.  `cur` is left untouched (the first add is not in place) and holds the scores the window
@@ -751,6 +745,9 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
             if (p_end > b0 + L.rows_per_block) p_end = b0 + L.rows_per_block;
         }
         if (p_begin >= p_end) return true;
+        // an abort request stops every item that has not started yet (the load travels with the item's first loads):
+        // a run of short models, whose items never reach the 2048-row poll below, drains at once too
+        if (abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
 
         uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_window)
         // (uniform base, lane offset added where it is used: a per-lane 64-bit pointer would sit in two VGPRs through the item)
