@@ -277,7 +277,12 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
             }
             L.rows_per_block = rows_per_block;
             const uint64_t nblocks_rows = (t.nrows_padded + rows_per_block - 1) / rows_per_block;
+            if (nblocks_rows * L.ntiles >= (1ull << 26)) { c->err = "too many tiles x row blocks for one launch"; return HAVAC_E_LENGTH; }
             L.nitems = (uint32_t)(nblocks_rows * L.ntiles);
+        }
+        if ((uint64_t)L.nitems * 64 >= (1ull << 32)) {      // a dispatch counts its work-items in 32 bits
+            c->err = "too many tiles x row blocks for one launch (" + std::to_string(L.nitems) + " items)";
+            return HAVAC_E_LENGTH;
         }
         nblocks = (uint32_t)(((uint64_t)L.nitems + kWavesPerBlock - 1) / kWavesPerBlock);
         if (split) {
@@ -309,6 +314,22 @@ using hit_sort_config = rocprim::radix_sort_config<rocprim::default_config, rocp
 
 // radix sort of `count` keys held in `keys` (in place via the alt buffer), on `stream`; only the low `key_bits`
 // bits can differ between keys
+static int sort_run(havac_ssv_ctx* c, uint64_t* keys, uint64_t* alt, uint64_t count, hipStream_t stream, unsigned key_bits) {
+    // `count` keys in `keys` -> sorted in `alt`
+    size_t need = 0;
+    HIP_TRY(c->err, rocprim::radix_sort_keys<hit_sort_config>(nullptr, need, keys, alt, (size_t)count, 0, key_bits, stream));
+    if (c->sort_tmp_bytes < need) {
+        HIP_TRY(c->err, hipStreamSynchronize(stream));        // an earlier run on this stream may still use the old one
+        if (c->sort_tmp) (void)hipFree(c->sort_tmp);
+        c->sort_tmp = nullptr; c->sort_tmp_bytes = 0;
+        HIP_TRY(c->err, hipMalloc(&c->sort_tmp, need + need / 4));
+        c->sort_tmp_bytes = need + need / 4;
+    }
+    size_t bytes = c->sort_tmp_bytes;
+    HIP_TRY(c->err, rocprim::radix_sort_keys<hit_sort_config>(c->sort_tmp, bytes, keys, alt, (size_t)count, 0, key_bits, stream));
+    return HAVAC_OK;
+}
+
 static int sort_keys(havac_ssv_ctx* c, uint64_t* keys, uint64_t count, hipStream_t stream, unsigned key_bits = 64) {
     if (count < 2) return HAVAC_OK;
     if (c->sort_alt_count < count) {
@@ -318,16 +339,9 @@ static int sort_keys(havac_ssv_ctx* c, uint64_t* keys, uint64_t count, hipStream
         HIP_TRY(c->err, hipMalloc(&c->sort_alt, want * sizeof(uint64_t)));
         c->sort_alt_count = want;
     }
-    size_t need = 0;
-    HIP_TRY(c->err, rocprim::radix_sort_keys<hit_sort_config>(nullptr, need, keys, c->sort_alt, (size_t)count, 0, key_bits, stream));
-    if (c->sort_tmp_bytes < need) {
-        if (c->sort_tmp) (void)hipFree(c->sort_tmp);
-        c->sort_tmp = nullptr; c->sort_tmp_bytes = 0;
-        HIP_TRY(c->err, hipMalloc(&c->sort_tmp, need + need / 4));
-        c->sort_tmp_bytes = need + need / 4;
-    }
-    size_t bytes = c->sort_tmp_bytes;
-    HIP_TRY(c->err, rocprim::radix_sort_keys<hit_sort_config>(c->sort_tmp, bytes, keys, c->sort_alt, (size_t)count, 0, key_bits, stream));
+    // (rocPRIM orders more than 2^32 keys in one call: 4.5e9 checked, tools/big_sort_check.py)
+    int rc = sort_run(c, keys, c->sort_alt, count, stream, key_bits);
+    if (rc) return rc;
     HIP_TRY(c->err, hipMemcpyAsync(keys, c->sort_alt, count * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
     return HAVAC_OK;
 }
@@ -348,8 +362,8 @@ extern "C" int havac_ssv_finish(havac_ssv_ctx* c, uint64_t* hit_count_out) {
     int rc = sort_keys(c, c->d_hits, stored, c->stream, c->key_bits);
     if (rc) return rc;
     if (stored)
-        hipLaunchKernelGGL(ssv_keys_to_records, dim3((unsigned)((stored + 255) / 256)), dim3(256), 0, c->stream,
-                           c->d_hits, stored, c->row_bits);
+        hipLaunchKernelGGL(ssv_keys_to_records, dim3((unsigned)std::min<uint64_t>((stored + 255) / 256, 1u << 20)), dim3(256), 0,
+                           c->stream, c->d_hits, stored, c->row_bits);
     HIP_TRY(c->err, hipEventRecord(c->ev[3], c->stream));
     HIP_TRY(c->err, hipStreamSynchronize(c->stream));
     HIP_TRY(c->err, hipEventElapsedTime(&c->ssv_ms, c->ev[1], c->ev[2]));
@@ -367,7 +381,7 @@ extern "C" int havac_ssv_sort_hits(havac_ssv_ctx* c, uint64_t* d_hits, uint64_t 
     if (count == 0) return HAVAC_OK;
     hipStream_t stream = (hipStream_t)hip_stream;
     HIP_TRY(c->err, hipSetDevice(c->device));
-    unsigned nb = (unsigned)((count + 255) / 256);
+    unsigned nb = (unsigned)std::min<uint64_t>((count + 255) / 256, 1u << 20);     // grid-stride kernels
     hipLaunchKernelGGL(ssv_records_to_keys, dim3(nb), dim3(256), 0, stream, d_hits, count, 24u);
     int rc = sort_keys(c, d_hits, count, stream);
     if (rc) return rc;

@@ -902,13 +902,15 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
 
 // ---------------------------------------------------------------------------
 // after the radix sort of the keys: rewrite them as the reference's records
+// (grid-stride: a launch holds fewer than 2^32 threads -- the dispatch packet counts work-items in 32 bits -- and C4 on
+// one GPU orders 4.5e9 records)
 __global__ void ssv_keys_to_records(uint64_t* __restrict__ hits, uint64_t n, uint32_t row_bits) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) hits[i] = key_to_record(hits[i], row_bits);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        hits[i] = key_to_record(hits[i], row_bits);
 }
 __global__ void ssv_records_to_keys(uint64_t* __restrict__ hits, uint64_t n, uint32_t row_bits) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) hits[i] = record_to_key(hits[i], row_bits);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        hits[i] = record_to_key(hits[i], row_bits);
 }
 
 }  // namespace havac

@@ -178,6 +178,21 @@ def test_sort_hits_entry_point(torch_dev, oracle):
     assert np.array_equal(got, oracle.device_order(recs))
 
 
+def test_ordering_more_than_2_to_32_records():
+    """C4 on ONE GPU orders 4.5e9 records in one list.  4.4e9 random records through havac_ssv_sort_hits: device order,
+    same multiset.  (Round 2 found the key <-> record kernels launched with one thread per record: a dispatch counts its
+    work-items in 32 bits, so beyond 2^32 records the tail of the list stayed unconverted.  They are grid-stride now.)
+    HIP through ctypes and numpy on the host: torch's own kernels mis-index tensors of more than 2^32 elements here."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "big_sort_check.py"), "4.4e9"], capture_output=True,
+                       text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "4400000000 records: same multiset True, out-of-order neighbours 0" in r.stdout, r.stdout[-500:]
+
+
 def test_columns_beyond_2_to_32(torch_dev, oracle):
     """5.0e9 columns (1.25 GB packed): more than the reference's 32-bit symbol count allows
     (host/HavacHwClient.cpp:81), inside the record format's 26-bit segment field.  Windows at both ends."""
