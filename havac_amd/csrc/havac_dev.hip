@@ -245,11 +245,9 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     while ((1u << row_bits) < t.nrows_padded + 2u) row_bits++;
     while ((1ull << seg_bits) < nsymbols / HAVAC_SEGMENT_COLUMNS) seg_bits++;
     // ---- how the tiles are handed out (ssv_kernels.hip.h, "work distribution") ----
-    SsvLaunch L{};
-    L.nsymbols = (int64_t)nsymbols; L.nrows_padded = t.nrows_padded;
+    SsvRare L{};          // the kernel's first argument: tiling, hit queue, hand-off buffers (read from the kernarg segment on demand)
     L.first_diag = t.first_diag; L.tile_begin = tb; L.ntiles = te - tb;
-    L.col_begin = (int64_t)col_begin; L.col_end = (int64_t)col_end;
-    L.hit_capacity = hit_capacity; L.row_bits = row_bits;
+    L.col_end = (int64_t)col_end;
     // Row blocks (ssv_kernels.hip.h, "work distribution"): tiles taller than a block are cut into blocks of
     // kRowsPerBlock rows when there are fewer of them than kSplitBelowRounds rounds of wave slots (measured, kernel
     // only: C3 as stated 42.4 -> 54.0 TCUPS, C5 53.0 -> 54.6; blocks of 4096 / 16384 rows: 53.6 / 53.6 and 54.0 / 54.7).  (Cutting SHORT
@@ -263,9 +261,21 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         if (rows_per_block >= t.nrows_padded) rows_per_block = 0;
     }
     const bool split = rows_per_block != 0;
+    // Short models: a wave walks several adjacent tiles (ssv_kernels.hip.h, "items") -- as many as make ~256 rows of work,
+    // at most 8, and never so many that fewer than four rounds of wave slots are left to balance the chip.
+    uint32_t tiles_per_item = 1;
+    if (!split && te > tb && t.nrows_padded <= 128) {
+        const uint64_t by_rounds = L.ntiles / (4 * slots);
+        tiles_per_item = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({8, 256 / t.nrows_padded, by_rounds}));
+    }
+    if (const char* forced = std::getenv("HAVAC_TILES_PER_ITEM")) {           // experiments
+        tiles_per_item = (uint32_t)std::max(1, std::atoi(forced));
+        if (split) tiles_per_item = 1;
+    }
+    L.tiles_per_item = tiles_per_item;
     uint32_t nblocks = 0;
     if (te > tb) {
-        L.nitems = L.ntiles;
+        L.nitems = (L.ntiles + tiles_per_item - 1) / tiles_per_item;
         if (split) {
             if (c->block_flag_tiles < L.ntiles) {
                 if (c->block_flags) (void)hipFree(c->block_flags);
@@ -291,11 +301,16 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         }
     }
     HIP_TRY(c->err, hipEventRecord(c->ev[1], stream));
-    if (te > tb)
-        hipLaunchKernelGGL(ssv_diag_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream,
+    if (te > tb) {
+        SsvRare& R = L;
+        R.hits = d_hits; R.hit_count = c->d_count; R.hit_capacity = hit_capacity;
+        R.col_begin = (int64_t)col_begin; R.col_span = col_end - col_begin;
+        R.abort_flag = d_abort_flag; R.pair_mask = c->pair_mask; R.tickets = c->tickets; R.block_flags = c->block_flags; R.block_state = c->block_state;
+        R.fault = c->tickets + kTicketCounters * kTicketStride; R.row_bits = row_bits;
+        hipLaunchKernelGGL(ssv_diag_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,
                            d_sequence, (const uint32_t*)c->rows8, c->pair_mask ? (const uint32_t*)nullptr : (const uint32_t*)c->chunk_flags,
-                           c->pair_mask, d_abort_flag, d_hits, c->d_count, c->tickets, c->block_flags, c->block_state,
-                           c->tickets + kTicketCounters * kTicketStride, L);
+                           (int64_t)nsymbols, t.nrows_padded);
+    }
     HIP_TRY(c->err, hipEventRecord(c->ev[2], stream));
     HIP_TRY(c->err, hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     // the kernel's fault word (a row-block hand-off that never came): never expected, but never waited for silently either

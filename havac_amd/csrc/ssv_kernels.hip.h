@@ -269,6 +269,9 @@ __global__ void ssv_reverse_strand(uint32_t* __restrict__ packed, uint64_t nf, c
 }
 
 // ---------------------------------------------------------------------------
+#ifndef HAVAC_GROUP_WAIT
+#define HAVAC_GROUP_WAIT
+#endif
 typedef short short2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) u32x2* lds_words_t;
@@ -278,6 +281,9 @@ typedef __attribute__((address_space(3))) u32x2* lds_words_out_t;
 struct __attribute__((aligned(128))) WaveLds {
     uint8_t table[kTableBytes];            // match words of the current chunk
     uint64_t stage[kHitStage];             // records waiting for the next burst
+#ifdef HAVAC_EXPERIMENT_TIME_SLOW
+    unsigned long long dbg[2];
+#endif
 };
 
 // ---- hit queue --------------------------------------------------------------
@@ -287,13 +293,41 @@ struct __attribute__((aligned(128))) WaveLds {
 // queue in bursts: one returning atomic per burst instead of one per hit (a single
 // counter word sustains only ~90 returning atomics per microsecond chip-wide, which
 // capped the first version of this kernel at ~90 M hits/s).
-struct HitSink {
+// What the kernel needs RARELY -- when a hit is reported, a stage is flushed, a row block handed over, an abort polled --
+// is not kept in SGPRs through the hot loop (with it there the kernel needed ~130 SGPRs: hipcc parked 30 of them in the
+// lanes of a VGPR and fetched them back with ~10 v_readlane per chunk).  It is the kernel's FIRST argument, never named
+// in the kernel, and read from the kernarg segment (scalar loads, constant cache) where it is used.
+struct SsvRare {
     uint64_t* hits;                // global queue of sort keys (hit_key)
     unsigned long long* hit_count; // records found so far (may run past capacity)
     uint64_t hit_capacity;
-    WaveLds* lds;
-    int64_t col_begin, col_end;    // only hits in these columns are reported (the shard's own columns)
+    int64_t col_begin;             // only hits in columns [col_begin, col_begin + col_span) are reported (the shard's own columns)
+    uint64_t col_span;
+    const uint32_t* abort_flag;    // optional device word: non-zero = stop
+    const uint16_t* pair_mask;     // separator bitmap (boundary mode); the kernel is given safe_chunks == nullptr exactly when it is set
+    uint32_t* tickets;             // the ticket counter of row-split launches
+    uint32_t* block_flags;         // per tile of this launch: row blocks finished
+    uint32_t* block_state;         // per tile: 16 x 64 scores handed from one row block to the next
+    uint32_t* fault;               // raised when a wait for a row block ran out (never expected)
     uint32_t row_bits;             // width of the row field of the sort key
+    // the tiling of this launch: read once per item (see "work distribution" below)
+    int64_t first_diag; uint32_t tile_begin, ntiles;
+    int64_t col_end;
+    uint32_t nitems;               // tiles, or tiles x row blocks, or groups of tiles_per_item tiles
+    uint32_t rows_per_block;       // 0: tiles are not split by rows (an item is a tile); else a multiple of 1024
+    uint32_t tiles_per_item;       // >= 1; > 1 only for short models (rows_per_block == 0): a wave walks that many ADJACENT tiles,
+                                   // and what it staged leaves with one atomic per block at the end of all of them
+};
+typedef const __attribute__((address_space(4))) SsvRare* rare_args_t;
+// (opaque: the loads through it stay where they are written instead of being hoisted to the kernel's entry)
+__device__ __forceinline__ rare_args_t rare_args() {
+    rare_args_t p = (rare_args_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+struct HitSink {
+    WaveLds* lds;
 };
 
 // A staged record is (row << 40 | column): two scalar instructions in the slow path; the sort key (a division by
@@ -302,26 +336,30 @@ __device__ __forceinline__ uint64_t staged_to_key(uint64_t staged_record, uint32
     return hit_key((uint32_t)(staged_record >> 40), staged_record & ((1ull << 40) - 1ull), row_bits);
 }
 
-__device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, uint32_t staged) {
+__device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, const rare_args_t rare, uint32_t staged) {
     if (staged == 0) return 0;
     const uint32_t lane = __lane_id();
+    uint64_t* const hits = rare->hits;
+    const uint64_t capacity = rare->hit_capacity;
+    const uint32_t row_bits = rare->row_bits;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(sink.hit_count, (unsigned long long)staged);
+    if (lane == 0) base = atomicAdd(rare->hit_count, (unsigned long long)staged);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
     base = ((unsigned long long)hi << 32) | lo;
     for (uint32_t i = lane; i < staged; i += 64) {
         const unsigned long long idx = base + i;
-        if (idx < sink.hit_capacity) sink.hits[idx] = staged_to_key(sink.lds->stage[i], sink.row_bits);
+        if (idx < capacity) hits[idx] = staged_to_key(sink.lds->stage[i], row_bits);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     return 0;
 }
 
 // A full stage leaves with one returning atomic (a real call: rare, and its registers stay out of the hot loop).
-__device__ __noinline__ uint32_t flush_full(const HitSink sink, uint32_t staged) {
-    return flush_hits(sink, __builtin_amdgcn_readfirstlane(staged));
+// (the kernarg pointer is handed in: in a function that is really called, __builtin_amdgcn_kernarg_segment_ptr() is null)
+__device__ __noinline__ uint32_t flush_full(const HitSink sink, const rare_args_t rare, uint32_t staged) {
+    return flush_hits(sink, rare, __builtin_amdgcn_readfirstlane(staged));
 }
 
 // The slow path's copy of one half of v_pk_add_i16 ... clamp, on the scalar unit: the cell and its match score are kept
@@ -335,16 +373,18 @@ __device__ __forceinline__ int32_t scalar_sat_add(int32_t a, int32_t b) {
 }
 
 // One record of the slow path: cell (row, column), wave-uniform.  Staged as (row << 40 | column) by lane 0.
-__device__ __forceinline__ uint32_t emit_cell(const HitSink& sink, uint32_t staged, uint32_t row, int64_t column) {
+struct ShardColumns { rare_args_t rare; int64_t begin; uint64_t span; };     // read at the slow path's entry, used when a cell is reported
+__device__ __forceinline__ uint32_t emit_cell(const HitSink& sink, const ShardColumns& own, uint32_t staged, uint32_t row, int64_t column) {
     // halo columns belong to the neighbouring shard: one unsigned comparison of (column - col_begin) with the span
-    if ((uint64_t)(column - sink.col_begin) < (uint64_t)(sink.col_end - sink.col_begin)) {
+    const rare_args_t rare = own.rare;
+    if ((uint64_t)(column - own.begin) < own.span) {
         const uint64_t record = ((uint64_t)row << 40) | (uint64_t)column;
         const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint64_t*)sink.lds->stage + staged * 8;
         uint64_t saved_exec;        // one lane stores: exec = lane 0 for the one instruction
         asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b64 %1, %2\n\ts_mov_b64 exec, %0"
                      : "=&s"(saved_exec) : "v"(addr), "v"(record) : "memory");
         staged++;
-        if (staged == kHitStage) staged = flush_full(sink, staged);
+        if (staged == kHitStage) staged = flush_full(sink, rare, staged);
     }
     return staged;
 }
@@ -353,6 +393,25 @@ __device__ __forceinline__ uint32_t emit_cell(const HitSink& sink, uint32_t stag
 template <int P>
 __device__ __forceinline__ u32x2 match_words(uint32_t code_addr) {
     return *(lds_words_t)(uintptr_t)(code_addr + P * kPairStride);
+}
+
+// A wave-uniform 32-bit value the optimiser cannot see through, kept in an SGPR.  Two uses: (a) 64-bit comparisons of
+// uniform values are done on the VALU (there is no s_cmp_lt_i64) unless they are taken apart into 32-bit halves that the
+// optimiser cannot put together again; (b) a uniform flag that lives across the chunk loop is otherwise kept as a lane
+// mask and converted back and forth through a VGPR (v_cndmask + v_cmp per use).
+__device__ __forceinline__ uint32_t opaque_uniform(uint32_t x) {
+    x = __builtin_amdgcn_readfirstlane(x);      // a copy where the value is in an SGPR already
+    asm("" : "+s"(x));
+    return x;
+}
+// The same, evaluated afresh at every use: a uniform flag tested in several basic blocks is otherwise turned into ONE lane mask
+// whose copies and inversions go through a VGPR (v_cndmask + v_cmp per block); tested afresh it is s_cmp + s_cbranch_scc.
+__device__ __forceinline__ uint32_t fresh_uniform(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
+// v clamped to [0, 4096], on the scalar unit
+__device__ __forceinline__ int32_t clamp_to_4096(int64_t v) {
+    const int32_t hi = (int32_t)opaque_uniform((uint32_t)((uint64_t)v >> 32));
+    const uint32_t lo = opaque_uniform((uint32_t)v);
+    return hi < 0 ? 0 : ((hi > 0 || lo > 4096u) ? 4096 : (int32_t)lo);
 }
 
 // ---- the symbol window, expanded as the windows reach it --------------------------------------------------------
@@ -365,7 +424,7 @@ struct LazySymbols {
     uint32_t even[2], odd[2];   // per packed word (pairs 16..23, 24..31): code*8 of its even / odd pairs, one per byte
     uint32_t separators;        // bit K: pair 16+K is a separator pair (boundary mode); 0 otherwise
     uint32_t table_base;
-    bool special;               // wave-uniform: some position of the wave lies outside [0, N), or a separator is present
+    uint32_t special;           // wave-uniform, 0 or 1 (a 32-bit SGPR, not a lane mask): some position of the wave lies outside [0, N), or a separator is present
     uint32_t lane8;             // 8 * lane; 32 * lane is the lane's first position relative to the wave's (only read when special)
     int32_t valid_lo, valid_hi; // wave-uniform: positions relative to the wave's first that lie inside [0, N): [valid_lo, valid_hi)
 };
@@ -390,7 +449,7 @@ template <int K>
 __device__ __forceinline__ void expand_entry(uint32_t (&C)[32], const LazySymbols& z) {
     constexpr int n = K & 7;
     uint32_t entry = or_byte<n / 2>(z.table_base, (n & 1) ? z.odd[K / 8] : z.even[K / 8]);
-    if (z.special) {
+    if (fresh_uniform(z.special)) {
         // positions outside [0, N) and separator pairs use the 17th entry of the tables
         uint32_t lane32 = z.lane8 * 4;
         asm volatile("" : "+v"(lane32));                        // computed here, in the rare chunks that need it: hipcc otherwise
@@ -417,6 +476,9 @@ __device__ __forceinline__ void expand_all(uint32_t (&C)[32], const LazySymbols&
     (expand_entry<K>(C, z), ...);
 }
 
+#ifdef HAVAC_EXPERIMENT_TIME_SLOW
+__device__ unsigned long long g_slow_cycles, g_slow_calls, g_item_cycles, g_items;
+#endif
 // ---- the slow path ------------------------------------------------------------------------------------------------
 // What the slow path of a window needs of register I of lane l: the scores the window started from and the LDS
 // addresses of the two table entries its four match words came from.  Selected by a chain of scalar compares on the
@@ -522,6 +584,17 @@ template <int Q, int NSTEPS, int... I>
 __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
                                             uint32_t marked, int report_from, const HitSink& sink, uint32_t& staged,
                                             uint32_t step0, int64_t wave_diag0, std::integer_sequence<int, I...>) {
+#ifdef HAVAC_SLOW_PRIO
+    __builtin_amdgcn_s_setprio(HAVAC_SLOW_PRIO);
+#endif
+#ifdef HAVAC_EXPERIMENT_TIME_SLOW
+    const long long t_in = clock64();
+#endif
+    // the shard's columns, from the kernarg segment: the loads are issued here and are back long before a cell is reported
+    ShardColumns own;
+    own.rare = rare_args();
+    own.begin = own.rare->col_begin;
+    own.span = own.rare->col_span;
     do {
         unsigned long long lanes = __ballot((marked & kCrossedBits) != 0);
         do {
@@ -545,14 +618,17 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
             // Only a cell that shows a mark crossed in these steps (a mark outlives them: that is what `safe` and the
             // middle test are for); the other cell of the register is exact as it stands.
             int32_t low = (int32_t)(s << 16), high = (int32_t)(s & 0xffff0000u);     // the register's two cells
+            // The replay only NOTES which steps crossed (bit k: the low cell at step k; bit 4 + k: the high cell) and has no
+            // branch in it; the records are made afterwards, in one place (eight inlined copies of the reporting code, with
+            // everything the optimiser hoisted out of them, cost the slow path 16 SGPRs and their spills).
+            uint32_t crossed = 0;
             if (now & 1u) {
 #pragma unroll
                 for (int k = 0; k < NSTEPS; k++) {
                     low = scalar_sat_add(low, (int32_t)(w[k] << 16));
-                    if (low == INT32_MAX) {           // crossed at (row t0 + k, column column0 + k)
-                        if (k >= report_from) staged = emit_cell(sink, staged, t0 + k, column0 + k);
-                        low = INT32_MIN;
-                    }
+                    const bool hit = low == INT32_MAX;            // crossed at (row t0 + k, column column0 + k)
+                    crossed |= hit ? (1u << k) : 0u;
+                    low = hit ? INT32_MIN : low;
                 }
                 now = (now & 0xffff0000u) | ((uint32_t)low >> 16);
             }
@@ -560,20 +636,35 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
 #pragma unroll
                 for (int k = 0; k < NSTEPS; k++) {
                     high = scalar_sat_add(high, (int32_t)(w[k] & 0xffff0000u));
-                    if (high == INT32_MAX) {          // the high cell: one row behind, the same column
-                        if (k >= report_from) staged = emit_cell(sink, staged, t0 + k - 1, column0 + k);
-                        high = INT32_MIN;
-                    }
+                    const bool hit = high == INT32_MAX;           // the high cell: one row behind, the same column
+                    crossed |= hit ? (16u << k) : 0u;
+                    high = hit ? INT32_MIN : high;
                 }
                 now = (now & 0xffffu) | ((uint32_t)high & 0xffff0000u);
+            }
+            crossed &= ((0xfu << report_from) & 0xfu) * 0x11u;      // steps before report_from were reported at the window's middle
+            while (crossed) {
+                const uint32_t bit = (uint32_t)__builtin_ctz(crossed);
+                crossed &= crossed - 1;
+                const uint32_t k = bit & 3u, behind = bit >> 2;
+                staged = emit_cell(sink, own, staged, t0 + k - behind, column0 + k);
             }
             s = now;
             write_score_lane(nxt, s, l, r);
         } while (lanes);
+#ifdef HAVAC_EXPERIMENT_NO_RECHECK
+        break;
+#endif
         marked = 0;
 #pragma unroll
         for (int i = 0; i < kRegs; i++) marked |= nxt[i];
     } while (__any((marked & kCrossedBits) != 0));
+#ifdef HAVAC_SLOW_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef HAVAC_EXPERIMENT_TIME_SLOW
+    if (__lane_id() == 0) { sink.lds->dbg[0] += (unsigned long long)(clock64() - t_in); sink.lds->dbg[1] += 1ull; }
+#endif
 }
 
 // Steps 4Q .. 4Q+3 of the chunk.  `cur` is left untouched (the first add is not in place) and holds the scores the window
@@ -581,7 +672,7 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
 // the end where ssv_chunk_flags says that is exact (`safe`, wave-uniform), else one more in the middle.
 template <int Q, int... I>
 __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
-                                            bool safe, const HitSink& sink, uint32_t& staged, uint32_t step0,
+                                            uint32_t safe, const HitSink& sink, uint32_t& staged, uint32_t step0,
                                             int64_t wave_diag0, std::integer_sequence<int, I...> regs) {
     static_assert(sizeof...(I) == kRegs, "one index per score register");
     constexpr int H = kRegs / 2;            // match words are read for eight registers at a time: 16 VGPRs in flight, not 32
@@ -593,12 +684,13 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
 #pragma unroll
         for (int i = 0; i < H; i++) m[i] = match_words<2 * Q>(C[2 * Q + h * H + i]);
         __builtin_amdgcn_sched_barrier(0);      // all eight reads in flight before the first add waits (hipcc otherwise staggers them)
+        HAVAC_GROUP_WAIT
 #pragma unroll
         for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(nxt[h * H + i]) : "v"(cur[h * H + i]), "v"(m[i].x));
 #pragma unroll
         for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[h * H + i]) : "v"(m[i].y));
     }
-    if (!safe) {
+    if (!fresh_uniform(safe)) {
         uint32_t any = 0;
 #pragma unroll
         for (int i = 0; i < kRegs; i++) any |= nxt[i];
@@ -613,6 +705,7 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
 #pragma unroll
         for (int i = 0; i < H; i++) m[i] = match_words<2 * Q + 1>(C[2 * Q + 1 + h * H + i]);
         __builtin_amdgcn_sched_barrier(0);
+        HAVAC_GROUP_WAIT
 #pragma unroll
         for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[h * H + i]) : "v"(m[i].x));
 #pragma unroll
@@ -622,7 +715,7 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
 #pragma unroll
     for (int i = 0; i < kRegs; i++) any |= nxt[i];
     if (__builtin_expect(__any((any & kCrossedBits) != 0), 0))
-        window_slow<Q, kWindowSteps>(cur, nxt, C, any, safe ? 0 : 2, sink, staged, step0, wave_diag0, regs);
+        window_slow<Q, kWindowSteps>(cur, nxt, C, any, (int)(2u - 2u * safe), sink, staged, step0, wave_diag0, regs);
 }
 
 // ONE step with the tables of step pair 0 (the step behind the model's last chunk: the high cells run one row behind
@@ -652,7 +745,7 @@ __device__ __forceinline__ void step_last(const uint32_t (&cur)[kRegs], uint32_t
 // windows 0 .. N-1 of a chunk; the scores are in `a` on entry and, N being even, in `a` again on exit
 template <int... Q>
 __device__ __forceinline__ void step_windows(uint32_t (&a)[kRegs], uint32_t (&b)[kRegs], uint32_t (&C)[32],
-                                             const LazySymbols& z, bool safe, const HitSink& sink, uint32_t& staged,
+                                             const LazySymbols& z, uint32_t safe, const HitSink& sink, uint32_t& staged,
                                              uint32_t step0, int64_t wave_diag0, std::integer_sequence<int, Q...>) {
     static_assert(sizeof...(Q) % 2 == 0 && sizeof...(Q) * kWindowSteps == kChunkRows, "a whole chunk, an even number of windows");
     ((expand_for_window<Q>(C, z),
@@ -673,15 +766,6 @@ __device__ __forceinline__ uint32_t word_selector(uint32_t a) { return 0x040c000
 // wave with the next row block of that tile picks them up.  Items are numbered row-block-major and a block takes its
 // four item numbers from a ticket it draws when it starts, so the row block a wave waits for is held by a block that
 // has started, whatever order blocks are dispatched in: the wait always ends.
-struct SsvLaunch {                // the scalars of a launch (the pointers are kernel arguments of their own: only
-                                  // `const T* __restrict__` arguments are read with scalar loads)
-    int64_t nsymbols; uint32_t nrows_padded;
-    int64_t first_diag; uint32_t tile_begin, ntiles;
-    int64_t col_begin, col_end;
-    uint64_t hit_capacity; uint32_t row_bits;
-    uint32_t nitems;              // tiles, or tiles x row blocks
-    uint32_t rows_per_block;      // 0: tiles are not split by rows (an item is a tile); else a multiple of 1024
-};
 constexpr int kTicketStride = 16;          // the ticket counter and the fault word sit in cache lines of their own
 constexpr int kTicketCounters = 1;
 constexpr int kBlocksPerCu = 5;            // 5 blocks of 4 waves = 5 waves per SIMD
@@ -692,21 +776,17 @@ constexpr uint32_t kHandoffSpins = 1u << 26;   // x ~1 us: a minute, far beyond 
 
 // 5 waves per SIMD: 96 VGPRs.  cur 16 + nxt 16 + 32 match words in flight + ~19 window addresses + 4 prepared symbol words.
 __global__ __launch_bounds__(64 * kWavesPerBlock, 5)
-void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
-                     const uint32_t* __restrict__ safe_chunks, const uint16_t* __restrict__ pair_mask,
-                     const uint32_t* abort_flag, uint64_t* __restrict__ hits, unsigned long long* hit_count,
-                     uint32_t* tickets,          // ncounters words, kTicketStride words apart
-                     uint32_t* block_flags,      // per tile of this launch: row blocks finished
-                     uint32_t* block_state,      // per tile: 16 x 64 scores handed from one row block to the next
-                     uint32_t* fault,            // raised when a wait for a row block ran out (never expected)
-                     const SsvLaunch L) {
+void ssv_diag_kernel(const SsvRare /* read through rare_args(), never by name */,
+                     const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
+                     const uint32_t* __restrict__ safe_chunks /* null with a separator mask: every chunk then tests every two steps */,
+                     const int64_t nsymbols, const uint32_t nrows_padded) {
     __shared__ WaveLds wave_lds[kWavesPerBlock];
 
     const uint32_t lane = threadIdx.x & 63;
     // readfirstlane: everything derived from the tile index is wave-uniform (SALU branches, scalar address math)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds* const lds = &wave_lds[wave];
-    const HitSink sink{hits, hit_count, L.hit_capacity, lds, L.col_begin, L.col_end, L.row_bits};
+    const HitSink sink{lds};
     uint32_t staged = 0;          // wave-uniform
 
     // LDS byte address of this wave's tables (a multiple of 128: code*8 is OR-ed into it)
@@ -723,37 +803,50 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
         // Without separators it scores 0: a cell outside the matrix keeps what it has (0 before a diagonal enters at
         // column 0; behind the last column nothing is reported any more) and a mark is never lost there.  With a
         // separator mask the same entry scores -128: two of them reset every diagonal through a separator pair.
-        const uint32_t outside = pair_mask ? kOutsideReset : kOutsideNeutral;
+        const uint32_t outside = !safe_chunks ? kOutsideReset : kOutsideNeutral;
         *(lds_words_out_t)(uintptr_t)(table_base + my_pair * kPairStride + kOutsideCode) = u32x2{outside, outside};
     }
 
     // ---- one item: rows [row_begin, row_end) of tile `tile_in_launch` ----------------------------------------------
     auto run_item = [&](const uint32_t item) -> bool {        // false: stop (abort requested, or a hand-off never came)
+        const rare_args_t launch = rare_args();
+        const uint32_t rows_per_block = launch->rows_per_block;
         uint32_t tile_in_launch = item, block = 0;
-        if (L.rows_per_block) { block = item / L.ntiles; tile_in_launch = item - block * L.ntiles; }
-        const uint32_t tile = L.tile_begin + tile_in_launch;
-        const int64_t d0 = L.first_diag + (int64_t)tile * kTileDiags;     // wave's first diagonal
+        if (rows_per_block) { const uint32_t ntiles = launch->ntiles; block = item / ntiles; tile_in_launch = item - block * ntiles; }
+        const uint32_t tile = launch->tile_begin + tile_in_launch;
+        const int64_t d0 = launch->first_diag + (int64_t)tile * kTileDiags;     // wave's first diagonal
         // steps whose cells of this tile can lie inside the matrix
-        int64_t p_lo = -d0 - kTileDiags;                                // first chunk touching column >= 0
-        if (p_lo < 0) p_lo = 0;
-        int64_t p_hi = L.col_end - d0;                                  // first chunk entirely right of the shard's columns
-        if (p_hi > (int64_t)L.nrows_padded) p_hi = L.nrows_padded;
-        int64_t p_begin = p_lo, p_end = p_hi;                           // this item's share of them
-        if (L.rows_per_block) {
-            const int64_t b0 = (int64_t)block * L.rows_per_block;
+        // (rows fit 24 bits: once clamped to [0, nrows_padded] everything about rows is 32-bit scalar arithmetic)
+        int64_t lo64 = -d0 - kTileDiags;                                // first chunk touching column >= 0
+        if (lo64 < 0) lo64 = 0;
+        if (lo64 > (int64_t)nrows_padded) lo64 = nrows_padded;
+        int64_t hi64 = launch->col_end - d0;                                  // first chunk entirely right of the shard's columns
+        if (hi64 > (int64_t)nrows_padded) hi64 = nrows_padded;
+        if (hi64 < 0) hi64 = 0;
+        const uint32_t p_lo = __builtin_amdgcn_readfirstlane((uint32_t)lo64), p_hi = __builtin_amdgcn_readfirstlane((uint32_t)hi64);
+        uint32_t p_begin = p_lo, p_end = p_hi;                          // this item's share of them
+        if (rows_per_block) {
+            const uint32_t b0 = block * rows_per_block;
             if (p_begin < b0) p_begin = b0;
-            if (p_end > b0 + L.rows_per_block) p_end = b0 + L.rows_per_block;
+            if (p_end > b0 + rows_per_block) p_end = b0 + rows_per_block;
         }
         if (p_begin >= p_end) return true;
         // an abort request stops every item that has not started yet (the load travels with the item's first loads):
         // a run of short models, whose items never reach the 2048-row poll below, drains at once too
-        if (abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
+        {
+            const uint32_t* const abort_flag = rare_args()->abort_flag;
+            if (abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
+        }
 
         uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_window)
         // (uniform base, lane offset added where it is used: a per-lane 64-bit pointer would sit in two VGPRs through the item)
-        uint32_t* const tile_state = block_state + (size_t)tile_in_launch * (kRegs * 64);
         if (p_begin > p_lo) {
             // the rows above belong to the previous row block of this tile: wait for it, take over its scores
+            const rare_args_t rare = rare_args();
+            const uint32_t* const abort_flag = rare->abort_flag;
+            uint32_t* const block_flags = rare->block_flags;
+            uint32_t* const fault = rare->fault;
+            const uint32_t* const tile_state = rare->block_state + (size_t)tile_in_launch * (kRegs * 64);
             uint32_t spins = 0;
             while (__hip_atomic_load(block_flags + tile_in_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < block) {
                 __builtin_amdgcn_s_sleep(32);
@@ -785,26 +878,37 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
         // the wave's 512 bytes are consecutive: a uniform base and the lane's byte offset.
         auto fetch_symbols = [&](int64_t rel, LazySymbols& z) {
             const int64_t first = d0 + rel;                               // the wave's first position
-            const bool edge = (first < 0) || (first + kTileDiags > L.nsymbols);
+            // positions relative to `first` that lie inside [0, N), clamped to [0, 4096]: all of it on the scalar unit
+            z.valid_lo = clamp_to_4096(-first);
+            z.valid_hi = clamp_to_4096(nsymbols - first);
+            const uint32_t edge = (uint32_t)(z.valid_lo != 0) | (uint32_t)(z.valid_hi < kTileDiags);   // first < 0, or first + 2048 > N
             const uint8_t* const base = seq + (first >> 2);             // only dereferenced for lanes inside [0, N)
-            const int64_t lo = -first, hi = L.nsymbols - first;           // positions relative to `first` that are inside
-            z.valid_lo = __builtin_amdgcn_readfirstlane((int32_t)(lo < 0 ? 0 : (lo > 4096 ? 4096 : lo)));
-            z.valid_hi = __builtin_amdgcn_readfirstlane((int32_t)(hi < 0 ? 0 : (hi > 4096 ? 4096 : hi)));
             z.lane8 = lane8;
             z.table_base = table_base;
-            const bool inside = !edge || ((int32_t)(lane8 * 4) >= z.valid_lo && (int32_t)(lane8 * 4) + 32 <= z.valid_hi);
             uint2 w = make_uint2(0u, 0u);
-            if (inside) w = *reinterpret_cast<const uint2*>(base + lane8);
             z.separators = 0;
-            if (pair_mask && inside) z.separators = pair_mask[(first >> 5) + (lane8 >> 3)];
-            z.special = edge || (pair_mask && __any(z.separators != 0));
+            if (!edge) {                                                  // the usual case: one coalesced load, uniform base + lane offset
+                // (the offset is made opaque HERE so that its zero-extension is in this block, where instruction selection
+                // can fold it into the load's "SGPR base + 32-bit VGPR offset" form; hoisted out of the chunk loop it is a 64-bit
+                // VGPR pair and costs a v_lshl_add_u64 per load)
+                uint32_t offset = lane8;
+                asm volatile("" : "+v"(offset));
+                w = *reinterpret_cast<const uint2*>(base + offset);
+                if (!safe_chunks) z.separators = rare_args()->pair_mask[(first >> 5) + (lane8 >> 3)];
+            } else if ((int32_t)(lane8 * 4) >= z.valid_lo && (int32_t)(lane8 * 4) + 32 <= z.valid_hi) {
+                w = *reinterpret_cast<const uint2*>(base + lane8);
+                if (!safe_chunks) z.separators = rare_args()->pair_mask[(first >> 5) + (lane8 >> 3)];
+            }
+            uint32_t special = edge;                                      // from scalars and a ballot only: stays on the scalar unit
+            if (!safe_chunks) special |= __any(z.separators != 0) ? 1u : 0u;
+            z.special = opaque_uniform(special);
             prepare_symbols(z, w.x, w.y);
         };
         // A chunk's 16 step-pair tables: entry (a,b) of pair P = { word(step 2P, a), word(step 2P+1, b) } with
         // word(t, a) = (M[t][a] << 8) | (M[t-1][a] << 24); rows[] is shifted by one, so rows[t] is M[t-1].
         // Four lanes share a step pair: they fetch its three model rows and each writes the entries of one b.
         struct ModelRows { uint32_t r0, r1, r2, sel_second, entries; };
-        auto fetch_rows = [&](int64_t p0) -> ModelRows {
+        auto fetch_rows = [&](uint32_t p0) -> ModelRows {
             const uint4 mine = lane_consts[lane8 >> 3];
             const uint32_t* r = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(rows + p0) + mine.z);
             return ModelRows{r[0], r[1], r[2], mine.x, mine.y};
@@ -830,37 +934,41 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
         // The word of the current 1024 rows and, loaded a whole block ahead, the next one: the test never waits for memory
         uint32_t safe_now = safe_chunks ? safe_chunks[p_begin >> 10] : 0u;
         uint32_t safe_next = safe_chunks ? safe_chunks[(p_begin >> 10) + 1] : 0u;
-        for (int64_t p0 = p_begin; p0 < p_end; p0 += kChunkRows) {
+        for (uint32_t p0 = p_begin; p0 < p_end; p0 += kChunkRows) {
             if ((p0 & 1023) == 0 && p0 != p_begin) {
                 safe_now = safe_next;
                 safe_next = safe_chunks ? safe_chunks[(p0 >> 10) + 1] : 0u;
             }
             // abort: a device word, read past the caches every 2048 rows inside an item (and between items, below)
-            if (abort_flag && ((p0 & 2047) == 0) && p0 != p_begin &&
-                __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { go_on = false; break; }
+            if (((p0 & 2047) == 0) && p0 != p_begin) {
+                const uint32_t* const abort_flag = rare_args()->abort_flag;
+                if (abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { go_on = false; break; }
+            }
             build_tables(next_rows);
             // slide the window by 32 symbols
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-            const bool safe = (safe_now >> ((uint32_t)(p0 >> 5) & 31u)) & 1u;
-            step_windows(x, x2, C, z, safe, sink, staged, (uint32_t)p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
+            const uint32_t safe = opaque_uniform((safe_now >> ((p0 >> 5) & 31u)) & 1u);
+            step_windows(x, x2, C, z, safe, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
             asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the windows
             next_rows = fetch_rows(p0 + kChunkRows);              // rows[] has kModelSlack words behind the model
             fetch_symbols(p0 + kChunkRows + 32, z);
         }
         if (!go_on) return false;
-        if (p_end == (int64_t)L.nrows_padded) {
+        if (p_end == nrows_padded) {
             // the high cells run one row behind: one more step gives them the model's last row
             build_tables(next_rows);                               // fetched for p_end by the last chunk
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-            step_last(x, x2, C, sink, staged, (uint32_t)p_end, d0, std::make_integer_sequence<int, kRegs>{});
+            step_last(x, x2, C, sink, staged, p_end, d0, std::make_integer_sequence<int, kRegs>{});
         } else if (p_end < p_hi) {
             // the tile goes on in the next row block: hand the scores over (release: the stores, then the count)
+            const rare_args_t rare = rare_args();
+            uint32_t* const tile_state = rare->block_state + (size_t)tile_in_launch * (kRegs * 64);
 #pragma unroll
             for (int i = 0; i < kRegs; i++) tile_state[i * 64 + (lane8 >> 3)] = x[i];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (lane8 == 0) __hip_atomic_store(block_flags + tile_in_launch, block + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane8 == 0) __hip_atomic_store(rare->block_flags + tile_in_launch, block + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return true;
     };
@@ -872,14 +980,35 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
     // really started, whatever order the hardware dispatched them in, and the row block a wave waits for (a smaller
     // item number) is held by a block that has started.
     uint32_t first_item = blockIdx.x * kWavesPerBlock;
-    if (L.rows_per_block) {
+    const uint32_t split_rows = rare_args()->rows_per_block;
+    if (split_rows) {
         __shared__ uint32_t block_ticket;
-        if (threadIdx.x == 0) block_ticket = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) block_ticket = __hip_atomic_fetch_add(rare_args()->tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         first_item = __builtin_amdgcn_readfirstlane(block_ticket) * kWavesPerBlock;
     }
     const uint32_t item = first_item + wave;         // wave-uniform
-    if (item < L.nitems) run_item(item);
+    // Short models (host: tiles_per_item > 1): a tile of one or two chunks is mostly prologue, and every block that found a
+    // hit ends with a returning atomic on the one counter word, which sustains ~90 of them per microsecond chip-wide --
+    // at 100 Mbp x 32 rows the blocks ask for more than that.  A wave therefore walks several adjacent tiles.
+#ifdef HAVAC_EXPERIMENT_TIME_SLOW
+    const long long t_item = clock64();
+    if (__lane_id() == 0) lds->dbg[0] = lds->dbg[1] = 0;
+#endif
+    if (item < rare_args()->nitems) {
+        const uint32_t per_item = split_rows ? 1u : rare_args()->tiles_per_item;
+        for (uint32_t g = 0; g < per_item; g++) {
+            const uint32_t unit = split_rows ? item : item * per_item + g;      // a tile x row block, or a tile
+            if (!split_rows && unit >= rare_args()->ntiles) break;
+            if (!run_item(unit)) break;
+        }
+    }
+#ifdef HAVAC_EXPERIMENT_TIME_SLOW
+    if (__lane_id() == 0) { atomicAdd(&g_item_cycles, (unsigned long long)(clock64() - t_item)); atomicAdd(&g_items, 1ull);
+                            atomicAdd(&g_slow_cycles, lds->dbg[0]); atomicAdd(&g_slow_calls, lds->dbg[1]); }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        printf("slow path: %llu calls %llu cycles | items %llu cycles %llu\n", g_slow_calls, g_slow_cycles, g_items, g_item_cycles);
+#endif
 
     // What is still staged goes out with ONE returning atomic per block, not per wave: the single counter word
     // sustains ~90 returning atomics per microsecond chip-wide.
@@ -891,13 +1020,19 @@ void ssv_diag_kernel(const uint8_t* __restrict__ seq, const uint32_t* __restrict
     if (threadIdx.x == 0) {
         uint32_t total = 0;
         for (int w = 0; w < kWavesPerBlock; w++) total += block_staged[w];
-        block_base = total ? atomicAdd(hit_count, (unsigned long long)total) : 0ull;
+        block_base = total ? atomicAdd(rare_args()->hit_count, (unsigned long long)total) : 0ull;
     }
     __syncthreads();
-    unsigned long long base = block_base;
-    for (uint32_t w = 0; w < wave; w++) base += block_staged[w];
-    for (uint32_t i = lane_again; i < staged; i += 64)
-        if (base + i < L.hit_capacity) hits[base + i] = staged_to_key(lds->stage[i], L.row_bits);
+    if (staged) {
+        const rare_args_t rare = rare_args();
+        uint64_t* const hits = rare->hits;
+        const uint64_t capacity = rare->hit_capacity;
+        const uint32_t row_bits = rare->row_bits;
+        unsigned long long base = block_base;
+        for (uint32_t w = 0; w < wave; w++) base += block_staged[w];
+        for (uint32_t i = lane_again; i < staged; i += 64)
+            if (base + i < capacity) hits[base + i] = staged_to_key(lds->stage[i], row_bits);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 """Kernel time against model height (32-row chunks per tile) on 100 Mbp, with a model that cannot hit and with the
-Dfam-like one.   python tools/rows_probe.py"""
+Dfam-like one.   python tools/rows_probe.py [rows ...]"""
 import os
 import sys
 
@@ -16,7 +16,8 @@ ncols = 100_012_032
 packed = synth.random_packed(ncols, synth.SEED_SEQUENCE)
 d_seq = torch.from_numpy(packed).to(dev)
 eng = ShardedSsv(1 << 23, dev)
-for nrows in (32, 64, 96, 128, 160, 192, 256, 384, 512, 1024):
+heights = [int(a) for a in sys.argv[1:]] or [32, 64, 96, 128, 160, 192, 256, 384, 512, 1024]
+for nrows in heights:
     out = []
     for kind in ("nohit", "dfam"):
         model = synth.dfam_like_model(nrows, synth.SEED_MODEL)[0] if kind == "dfam" else np.full((nrows, 4), -3, np.int8)
