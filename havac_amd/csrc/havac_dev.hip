@@ -99,7 +99,8 @@ struct havac_ssv_ctx {
     uint64_t* sort_alt = nullptr; size_t sort_alt_count = 0;
     unsigned long long* d_count = nullptr;
     unsigned long long* h_count = nullptr;     // pinned
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pass start, kernel start, kernel end, records ordered, count on the host
+    hipStream_t order_stream = nullptr;        // optional: where finish() orders the records (default: the enqueue's stream)
     // the pass enqueue() started and finish() completes
     bool pending = false;
     hipStream_t stream = nullptr;
@@ -167,6 +168,13 @@ extern "C" int havac_ssv_set_separator_mask(havac_ssv_ctx* c, const uint8_t* d_p
     if (!c) return HAVAC_E_ARGUMENT;
     if (((uintptr_t)d_pair_mask & 1u)) { c->err = "separator mask must be 2-byte aligned"; return HAVAC_E_ARGUMENT; }
     c->pair_mask = reinterpret_cast<const uint16_t*>(d_pair_mask);
+    return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_set_order_stream(havac_ssv_ctx* c, void* hip_stream) {
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (c->pending) { c->err = "a pass is in flight: set the ordering stream between passes"; return HAVAC_E_LOGIC; }
+    c->order_stream = (hipStream_t)hip_stream;
     return HAVAC_OK;
 }
 
@@ -315,6 +323,7 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     HIP_TRY(c->err, hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     // the kernel's fault word (a row-block hand-off that never came): never expected, but never waited for silently either
     HIP_TRY(c->err, hipMemcpyAsync(c->h_count + 1, c->tickets + kTicketCounters * kTicketStride, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c->err, hipEventRecord(c->ev[4], stream));       // finish() waits for THIS, not for the stream: later passes may be queued behind it
     HIP_TRY(c->err, hipGetLastError());
     c->pending = true; c->stream = stream; c->d_hits = d_hits; c->hit_capacity = hit_capacity;
     c->row_bits = row_bits;
@@ -366,7 +375,8 @@ extern "C" int havac_ssv_finish(havac_ssv_ctx* c, uint64_t* hit_count_out) {
     if (!c->pending) { c->err = "no pass enqueued"; return HAVAC_E_LOGIC; }
     c->pending = false;
     HIP_TRY(c->err, hipSetDevice(c->device));
-    HIP_TRY(c->err, hipStreamSynchronize(c->stream));
+    HIP_TRY(c->err, hipEventSynchronize(c->ev[4]));
+    const hipStream_t order = c->order_stream ? c->order_stream : c->stream;     // the kernel is done: no device-side dependency needed
     uint64_t found = *c->h_count;
     if ((uint32_t)c->h_count[1] != 0) {
         (void)hipMemsetAsync(c->tickets + kTicketCounters * kTicketStride, 0, sizeof(uint32_t), c->stream);
@@ -374,13 +384,13 @@ extern "C" int havac_ssv_finish(havac_ssv_ctx* c, uint64_t* hit_count_out) {
         return HAVAC_E_RUNTIME;
     }
     uint64_t stored = found < c->hit_capacity ? found : c->hit_capacity;
-    int rc = sort_keys(c, c->d_hits, stored, c->stream, c->key_bits);
+    int rc = sort_keys(c, c->d_hits, stored, order, c->key_bits);
     if (rc) return rc;
     if (stored)
         hipLaunchKernelGGL(ssv_keys_to_records, dim3((unsigned)std::min<uint64_t>((stored + 255) / 256, 1u << 20)), dim3(256), 0,
-                           c->stream, c->d_hits, stored, c->row_bits);
-    HIP_TRY(c->err, hipEventRecord(c->ev[3], c->stream));
-    HIP_TRY(c->err, hipStreamSynchronize(c->stream));
+                           order, c->d_hits, stored, c->row_bits);
+    HIP_TRY(c->err, hipEventRecord(c->ev[3], order));
+    HIP_TRY(c->err, hipStreamSynchronize(order));
     HIP_TRY(c->err, hipEventElapsedTime(&c->ssv_ms, c->ev[1], c->ev[2]));
     HIP_TRY(c->err, hipEventElapsedTime(&c->total_ms, c->ev[0], c->ev[3]));
     if (hit_count_out) *hit_count_out = found;

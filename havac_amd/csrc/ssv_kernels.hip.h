@@ -582,7 +582,7 @@ __device__ __forceinline__ void find_marked(uint32_t l, const uint32_t (&cur)[kR
 // c = wave_diag0 + 32 l + 2 r + t.
 template <int Q, int NSTEPS, int... I>
 __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
-                                            uint32_t marked, int report_from, const HitSink& sink, uint32_t& staged,
+                                            unsigned long long lanes, int report_from, const HitSink& sink, uint32_t& staged,
                                             uint32_t step0, int64_t wave_diag0, std::integer_sequence<int, I...>) {
 #ifdef HAVAC_SLOW_PRIO
     __builtin_amdgcn_s_setprio(HAVAC_SLOW_PRIO);
@@ -595,8 +595,7 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
     own.rare = rare_args();
     own.begin = own.rare->col_begin;
     own.span = own.rare->col_span;
-    do {
-        unsigned long long lanes = __ballot((marked & kCrossedBits) != 0);
+    do {                                  // `lanes`: the lanes that show a mark (the hit test's own comparison, handed in)
         do {
             const uint32_t l = (uint32_t)__builtin_ctzll(lanes);
             lanes &= lanes - 1;
@@ -655,10 +654,11 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
 #ifdef HAVAC_EXPERIMENT_NO_RECHECK
         break;
 #endif
-        marked = 0;
+        uint32_t marked = 0;
 #pragma unroll
         for (int i = 0; i < kRegs; i++) marked |= nxt[i];
-    } while (__any((marked & kCrossedBits) != 0));
+        lanes = __ballot((marked & kCrossedBits) != 0);
+    } while (lanes);
 #ifdef HAVAC_SLOW_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -694,8 +694,8 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
         uint32_t any = 0;
 #pragma unroll
         for (int i = 0; i < kRegs; i++) any |= nxt[i];
-        if (__builtin_expect(__any((any & kCrossedBits) != 0), 0))
-            window_slow<Q, 2>(cur, nxt, C, any, 0, sink, staged, step0, wave_diag0, regs);
+        if (const unsigned long long lanes = __ballot((any & kCrossedBits) != 0); __builtin_expect(lanes != 0, 0))
+            window_slow<Q, 2>(cur, nxt, C, lanes, 0, sink, staged, step0, wave_diag0, regs);
     }
     // steps 4Q+2, 4Q+3
 #pragma unroll
@@ -714,8 +714,8 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
     uint32_t any = 0;
 #pragma unroll
     for (int i = 0; i < kRegs; i++) any |= nxt[i];
-    if (__builtin_expect(__any((any & kCrossedBits) != 0), 0))
-        window_slow<Q, kWindowSteps>(cur, nxt, C, any, (int)(2u - 2u * safe), sink, staged, step0, wave_diag0, regs);
+    if (const unsigned long long lanes = __ballot((any & kCrossedBits) != 0); __builtin_expect(lanes != 0, 0))
+        window_slow<Q, kWindowSteps>(cur, nxt, C, lanes, (int)(2u - 2u * safe), sink, staged, step0, wave_diag0, regs);
 }
 
 // ONE step with the tables of step pair 0 (the step behind the model's last chunk: the high cells run one row behind
@@ -738,8 +738,8 @@ __device__ __forceinline__ void step_last(const uint32_t (&cur)[kRegs], uint32_t
     uint32_t any = 0;
 #pragma unroll
     for (int i = 0; i < kRegs; i++) any |= nxt[i];
-    if (__builtin_expect(__any((any & kCrossedBits) != 0), 0))
-        window_slow<0, 1>(cur, nxt, C, any, 0, sink, staged, step0, wave_diag0, regs);
+    if (const unsigned long long lanes = __ballot((any & kCrossedBits) != 0); __builtin_expect(lanes != 0, 0))
+        window_slow<0, 1>(cur, nxt, C, lanes, 0, sink, staged, step0, wave_diag0, regs);
 }
 
 // windows 0 .. N-1 of a chunk; the scores are in `a` on entry and, N being even, in `a` again on exit

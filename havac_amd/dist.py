@@ -83,8 +83,12 @@ class _Slot:
         from .ssv import SsvContext
         self.ctx = SsvContext()
         self.hits = torch.empty(hit_capacity, dtype=torch.int64, device=device)
-        self.stream = torch.cuda.Stream(device) if own_stream else None
-        self.kernel_done = None          # recorded behind the SSV kernel of the pass in flight
+        # the slot's own stream: the ordering of its records and their gather (low priority: what it runs fills the
+        # gaps the SSV kernels leave, it does not compete with them for compute units)
+        low, _high = torch.cuda.Stream.priority_range()
+        self.stream = torch.cuda.Stream(device, priority=low) if own_stream else None
+        if self.stream is not None:
+            self.ctx.set_order_stream(self.stream.cuda_stream)
         self.merged = None               # rank 0: receive buffer of the gather, grown on demand and kept
         self.gather_events = None        # (before, after) on the stream the gather ran on
 
@@ -92,27 +96,27 @@ class _Slot:
 class ShardedSsv:
     """Rank-local driver: enqueue this rank's shard, order its hits, gather to rank 0 (already in order).
 
-    depth > 1 keeps that many passes in flight, each with its own context, hit buffer and HIP stream:
+    depth > 1 keeps that many passes in flight, each with its own context, hit buffer and ordering stream:
     ``submit`` enqueues a pass, ``collect`` finishes the oldest one.  While the host waits for pass k's hit count,
     orders its records and (N > 1) gathers them over RCCL, the SSV kernel of pass k+1 is already running.  The SSV
-    kernels themselves are kept back to back, never side by side (pass k+1 waits for the kernel of pass k), so a
+    kernels of all passes are enqueued on ONE high-priority stream: back to back, never side by side, and never
+    behind another pass's ordering (havac_ssv_set_order_stream puts that on the slot's own low-priority stream), so a
     kernel's event-timed duration stays the duration of that kernel alone.
 
     The records ``collect`` returns live in the slot's receive buffer (world > 1) or hit buffer (world == 1): they
     are valid until that slot is submitted again, and the caller's current stream has been made to wait for them."""
 
-    def __init__(self, hit_capacity: int, device: torch.device, depth: int = 1, back_to_back: bool = True,
-                 gather_when_alone: bool = False):
+    def __init__(self, hit_capacity: int, device: torch.device, depth: int = 1, gather_when_alone: bool = False):
         self.device = device
-        self.back_to_back = back_to_back
         # rehearsals on one GPU: run the collectives even in a one-rank group
         self.gather_when_alone = gather_when_alone and dist.is_initialized()
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.slots = [_Slot(hit_capacity, device, depth > 1) for _ in range(max(1, depth))]
+        _low, high = torch.cuda.Stream.priority_range()
+        self.kernel_stream = torch.cuda.Stream(device, priority=high) if depth > 1 else None
         self.in_flight = []               # slot indices, oldest first
         self.next_slot = 0
-        self.last_kernel_done = None
         self.ctx = self.slots[0].ctx      # the context of the most recently collected pass (for last_ms)
         self.hits = self.slots[0].hits
         self.gather_ms = []               # device time of each gather on this rank (filled by gather_times())
@@ -122,17 +126,12 @@ class ShardedSsv:
         if len(self.in_flight) == len(self.slots):
             raise RuntimeError("every slot is in flight: collect() first")
         slot = self.slots[self.next_slot]
-        stream = slot.stream if slot.stream is not None else torch.cuda.current_stream(self.device)
-        if slot.stream is not None:
+        stream = self.kernel_stream if self.kernel_stream is not None else torch.cuda.current_stream(self.device)
+        if self.kernel_stream is not None:
             stream.wait_stream(torch.cuda.current_stream(self.device))      # the caller's inputs
-            if self.back_to_back and self.last_kernel_done is not None:
-                stream.wait_event(self.last_kernel_done)
+            stream.wait_stream(slot.stream)                                  # the slot's last gather has read its hit buffer
         slot.ctx.enqueue(d_seq.data_ptr(), nsymbols, d_phmm.data_ptr(), nrows, slot.hits.data_ptr(),
                          slot.hits.numel(), self.rank, self.world, 0, stream.cuda_stream)
-        if slot.stream is not None:
-            slot.kernel_done = torch.cuda.Event()
-            slot.kernel_done.record(stream)
-            self.last_kernel_done = slot.kernel_done
         self.in_flight.append(self.next_slot)
         self.next_slot = (self.next_slot + 1) % len(self.slots)
 

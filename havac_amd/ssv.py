@@ -37,6 +37,10 @@ class SsvContext:
         self._check(self._L.havac_ssv_enqueue(self._h, d_sequence, nsymbols, d_phmm, nrows, shard_index, shard_count,
                                               d_hits, hit_capacity, d_abort_flag or None, stream or None))
 
+    def set_order_stream(self, stream: int = 0):
+        """the HIP stream finish() orders the records on (0 = the stream of the enqueue)"""
+        self._check(self._L.havac_ssv_set_order_stream(self._h, stream or None))
+
     def finish(self) -> int:
         n = C.c_uint64(0)
         self._check(self._L.havac_ssv_finish(self._h, C.byref(n)))

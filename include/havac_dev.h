@@ -224,8 +224,15 @@ int havac_ssv_enqueue(havac_ssv_ctx *ctx, const uint8_t *d_sequence, uint64_t ns
  * alive, 2-byte aligned, nsymbols/16 bytes; NULL (the default) = none. */
 int havac_ssv_set_separator_mask(havac_ssv_ctx *ctx, const uint8_t *d_pair_bitmap);
 
+/* Optional: the HIP stream havac_ssv_finish orders the records on (NULL, the default = the stream of the enqueue).
+ * With passes in flight a caller keeps all SSV kernels back to back on ONE stream and gives every pass its own
+ * ordering stream: the kernel of pass k+1 then never waits behind the ordering of pass k (bench.py, havac_amd/dist.py).
+ * No counterpart in the reference (one run at a time, host/HavacHwClient.cpp:150-170). */
+int havac_ssv_set_order_stream(havac_ssv_ctx *ctx, void *hip_stream);
+
 /* Completes the enqueued pass: waits for it, puts the shard's records in
- * d_hits into device order (radix sort on the same stream) and returns the
+ * d_hits into device order (radix sort on the enqueue's stream, or on the
+ * ordering stream set above) and returns the
  * number of hits found.  If that exceeds hit_capacity only hit_capacity
  * records were kept and the result is HAVAC_E_HIT_OVERFLOW. */
 int havac_ssv_finish(havac_ssv_ctx *ctx, uint64_t *hit_count_out);
