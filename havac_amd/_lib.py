@@ -50,6 +50,7 @@ SIGNATURES = {
                                     C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "havac_ssv_set_separator_mask": (C.c_int, [_vp, C.c_void_p]),
     "havac_ssv_set_order_stream": (C.c_int, [_vp, C.c_void_p]),
+    "havac_ssv_set_cell_trace": (C.c_int, [_vp, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]),
     "havac_ssv_finish": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "havac_ssv_sort_hits": (C.c_int, [_vp, C.c_void_p, C.c_uint64, C.c_void_p]),
     "havac_ssv_last_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

@@ -100,6 +100,7 @@ struct havac_ssv_ctx {
     unsigned long long* d_count = nullptr;
     unsigned long long* h_count = nullptr;     // pinned
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pass start, kernel start, kernel end, records ordered, count on the host
+    CellRecord* trace_cells = nullptr; uint32_t trace_row0 = 0, trace_rows = 0, trace_cols = 0; uint64_t trace_col0 = 0;   // per-cell trace window (debugging)
     hipStream_t order_stream = nullptr;        // optional: where finish() orders the records (default: the enqueue's stream)
     // the pass enqueue() started and finish() completes
     bool pending = false;
@@ -168,6 +169,17 @@ extern "C" int havac_ssv_set_separator_mask(havac_ssv_ctx* c, const uint8_t* d_p
     if (!c) return HAVAC_E_ARGUMENT;
     if (((uintptr_t)d_pair_mask & 1u)) { c->err = "separator mask must be 2-byte aligned"; return HAVAC_E_ARGUMENT; }
     c->pair_mask = reinterpret_cast<const uint16_t*>(d_pair_mask);
+    return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_set_cell_trace(havac_ssv_ctx* c, havac_cell_record* d_cells, uint32_t row0, uint64_t col0,
+                                        uint32_t nrows, uint32_t ncols) {
+    static_assert(sizeof(havac_cell_record) == sizeof(CellRecord) && sizeof(CellRecord) == 8, "one layout on both sides of the ABI");
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (c->pending) { c->err = "a pass is in flight: set the trace window between passes"; return HAVAC_E_LOGIC; }
+    if (d_cells && (nrows == 0 || ncols == 0)) { c->err = "empty trace window"; return HAVAC_E_ARGUMENT; }
+    c->trace_cells = reinterpret_cast<CellRecord*>(d_cells);
+    c->trace_row0 = row0; c->trace_col0 = col0; c->trace_rows = nrows; c->trace_cols = ncols;
     return HAVAC_OK;
 }
 
@@ -315,9 +327,15 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         R.col_begin = (int64_t)col_begin; R.col_span = col_end - col_begin;
         R.abort_flag = d_abort_flag; R.pair_mask = c->pair_mask; R.tickets = c->tickets; R.block_flags = c->block_flags; R.block_state = c->block_state;
         R.fault = c->tickets + kTicketCounters * kTicketStride; R.row_bits = row_bits;
-        hipLaunchKernelGGL(ssv_diag_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,
-                           d_sequence, (const uint32_t*)c->rows8, c->pair_mask ? (const uint32_t*)nullptr : (const uint32_t*)c->chunk_flags,
-                           (int64_t)nsymbols, t.nrows_padded);
+        R.cells = c->trace_cells; R.cell_row0 = c->trace_row0; R.cell_col0 = (int64_t)c->trace_col0;
+        R.cell_rows = c->trace_rows; R.cell_cols = c->trace_cols;
+        const uint32_t* const safe_chunks = c->pair_mask ? (const uint32_t*)nullptr : (const uint32_t*)c->chunk_flags;
+        if (c->trace_cells)       // debugging: the same kernel body with the per-cell trace compiled in
+            hipLaunchKernelGGL(ssv_diag_kernel_traced, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,
+                               d_sequence, (const uint32_t*)c->rows8, safe_chunks, (int64_t)nsymbols, t.nrows_padded);
+        else
+            hipLaunchKernelGGL(ssv_diag_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,
+                               d_sequence, (const uint32_t*)c->rows8, safe_chunks, (int64_t)nsymbols, t.nrows_padded);
     }
     HIP_TRY(c->err, hipEventRecord(c->ev[2], stream));
     HIP_TRY(c->err, hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));

@@ -269,9 +269,6 @@ __global__ void ssv_reverse_strand(uint32_t* __restrict__ packed, uint64_t nf, c
 }
 
 // ---------------------------------------------------------------------------
-#ifndef HAVAC_GROUP_WAIT
-#define HAVAC_GROUP_WAIT
-#endif
 typedef short short2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) u32x2* lds_words_t;
@@ -281,9 +278,6 @@ typedef __attribute__((address_space(3))) u32x2* lds_words_out_t;
 struct __attribute__((aligned(128))) WaveLds {
     uint8_t table[kTableBytes];            // match words of the current chunk
     uint64_t stage[kHitStage];             // records waiting for the next burst
-#ifdef HAVAC_EXPERIMENT_TIME_SLOW
-    unsigned long long dbg[2];
-#endif
 };
 
 // ---- hit queue --------------------------------------------------------------
@@ -297,6 +291,27 @@ struct __attribute__((aligned(128))) WaveLds {
 // is not kept in SGPRs through the hot loop (with it there the kernel needed ~130 SGPRs: hipcc parked 30 of them in the
 // lanes of a VGPR and fetched them back with ~10 v_readlane per chunk).  It is the kernel's FIRST argument, never named
 // in the kernel, and read from the kernarg segment (scalar loads, constant cache) where it is used.
+// ---- per-cell trace ----------------------------------------------------------------------------------------------------
+// Counterpart of the reference's HAVAC_PER_CELL_DATA_TESTING build (device/PublicDefines.h:11): there every cell processor
+// records {prevValue, matchScore, cellValue, symbol, passesThreshold} (device/HavacHls.cpp:388-399) and
+// test/byCellComparator/byCellComparator.cpp:47-96 lays them next to softSsv's.  Here a second instantiation of the SAME
+// kernel body (ssv_diag_kernel_traced: same tables, symbol window, skewed pairs, saturating adds, slow path) writes, after
+// every single step, what each cell of a requested window went through -- decoded from the packed int16 form the kernel
+// really computes in, so the trace checks the representation, not a restatement of it.  A cell that crossed the threshold
+// keeps its mark until the window's hit test puts it back to score 0 (that is the design: one test per four steps), so
+// the up to three cells below a crossing on the same diagonal, inside the same window of four steps, are recorded with
+// `pending` set and carry no score; everything else is exact.
+struct CellRecord {
+    uint8_t prev;        // score of the cell above-left (the diagonal's previous cell)
+    int8_t match;        // match score that was added
+    uint8_t score;       // the cell's score afterwards (0 after a crossing, as device/HavacHls.cpp:384 has it)
+    uint8_t hit;         // 1: the cell crossed the threshold (passesThreshold)
+    uint8_t symbol;      // the sequence symbol the kernel used for the cell (0..3; 0xff under a separator)
+    uint8_t pending;     // 1: an earlier cell of this diagonal crossed inside the same four-step window; prev and score carry nothing
+    uint8_t zero;
+    uint8_t written;     // 1 (the caller clears the buffer: a cell the kernel never visited shows 0)
+};
+
 struct SsvRare {
     uint64_t* hits;                // global queue of sort keys (hit_key)
     unsigned long long* hit_count; // records found so far (may run past capacity)
@@ -317,9 +332,13 @@ struct SsvRare {
     uint32_t rows_per_block;       // 0: tiles are not split by rows (an item is a tile); else a multiple of 1024
     uint32_t tiles_per_item;       // >= 1; > 1 only for short models (rows_per_block == 0): a wave walks that many ADJACENT tiles,
                                    // and what it staged leaves with one atomic per block at the end of all of them
+    // per-cell trace (ssv_diag_kernel_traced only): one CellRecord per cell of rows [cell_row0, +cell_rows) x columns [cell_col0, +cell_cols)
+    struct CellRecord* cells; int64_t cell_col0; uint32_t cell_row0, cell_rows, cell_cols;
 };
 typedef const __attribute__((address_space(4))) SsvRare* rare_args_t;
-// (opaque: the loads through it stay where they are written instead of being hoisted to the kernel's entry)
+// (opaque: the loads through it stay where they are written instead of being hoisted to the kernel's entry.  Only valid in
+// code that is INLINED into the kernel: in a function that is really called __builtin_amdgcn_kernarg_segment_ptr() is null --
+// flush_full is handed the pointer, and the kernel body's item lambda is always_inline for this reason.)
 __device__ __forceinline__ rare_args_t rare_args() {
     rare_args_t p = (rare_args_t)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
@@ -476,9 +495,44 @@ __device__ __forceinline__ void expand_all(uint32_t (&C)[32], const LazySymbols&
     (expand_entry<K>(C, z), ...);
 }
 
-#ifdef HAVAC_EXPERIMENT_TIME_SLOW
-__device__ unsigned long long g_slow_cycles, g_slow_calls, g_item_cycles, g_items;
-#endif
+// One step of one register, traced: `before` and `after` are the register around the add of match word `mword`, `entry` the
+// table entry the word came from (table_base | code * 8, or the outside entry).  At step t the register's low cell is
+// (row t, column c) and its high cell (row t - 1, column c), c = wave_diag0 + 32 lane + 2 reg + t.
+// A REAL call (noinline): the traced body then stays about as big as the production one and is inlined the same way; the
+// window comes as arguments because a called function cannot read the kernarg segment (see rare_args).
+struct TraceWindow { CellRecord* cells; int64_t col0; uint32_t row0, nrows, ncols; };
+__device__ __noinline__ void trace_cells_of_step(TraceWindow win, uint32_t second_of_pair, uint32_t reg, uint32_t t, int64_t wave_diag0,
+                                                 uint32_t before, uint32_t mword, uint32_t after, uint32_t code) {
+    const int64_t column = wave_diag0 + (int64_t)(32u * __lane_id() + 2u * reg) + (int64_t)t;
+    const uint64_t dc = (uint64_t)(column - win.col0);
+    const uint8_t symbol = code > 15u ? 0xffu : (uint8_t)(second_of_pair ? code >> 2 : code & 3u);   // code: the symbol pair (a | b << 2); 16: outside / separator
+    for (uint32_t half = 0; half < 2; half++) {
+        const uint32_t dr = t - half - win.row0;                      // the high cell runs one row behind
+        if (dr < win.nrows && dc < (uint64_t)win.ncols) {
+            const uint32_t b = (before >> (16 * half)) & 0xffffu, a = (after >> (16 * half)) & 0xffffu;
+            CellRecord rec;
+            rec.pending = (b & 0xffu) != 0;                           // still marked from an earlier step of this window
+            rec.hit = !rec.pending && (a & 0xffu) != 0;
+            rec.prev = rec.pending ? 0 : (uint8_t)((b ^ 0x8000u) >> 8);
+            rec.score = (rec.pending || rec.hit) ? 0 : (uint8_t)((a ^ 0x8000u) >> 8);
+            rec.match = (int8_t)(uint8_t)(mword >> (8 + 16 * half));
+            rec.symbol = symbol;
+            rec.zero = 0;
+            rec.written = 1;
+            win.cells[(size_t)dr * win.ncols + (size_t)dc] = rec;
+        }
+    }
+}
+__device__ __forceinline__ TraceWindow trace_window() {          // inlined into the kernel: reads the kernarg segment
+    const rare_args_t rare = rare_args();
+    return TraceWindow{rare->cells, rare->cell_col0, rare->cell_row0, rare->cell_rows, rare->cell_cols};
+}
+template <bool SecondOfPair>
+__device__ __forceinline__ void trace_step(const TraceWindow& win, uint32_t reg, uint32_t t, int64_t wave_diag0, uint32_t before,
+                                           uint32_t mword, uint32_t after, uint32_t entry, uint32_t table_base) {
+    trace_cells_of_step(win, SecondOfPair ? 1u : 0u, reg, t, wave_diag0, before, mword, after, (entry - table_base) >> 3);
+}
+
 // ---- the slow path ------------------------------------------------------------------------------------------------
 // What the slow path of a window needs of register I of lane l: the scores the window started from and the LDS
 // addresses of the two table entries its four match words came from.  Selected by a chain of scalar compares on the
@@ -584,12 +638,6 @@ template <int Q, int NSTEPS, int... I>
 __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
                                             unsigned long long lanes, int report_from, const HitSink& sink, uint32_t& staged,
                                             uint32_t step0, int64_t wave_diag0, std::integer_sequence<int, I...>) {
-#ifdef HAVAC_SLOW_PRIO
-    __builtin_amdgcn_s_setprio(HAVAC_SLOW_PRIO);
-#endif
-#ifdef HAVAC_EXPERIMENT_TIME_SLOW
-    const long long t_in = clock64();
-#endif
     // the shard's columns, from the kernarg segment: the loads are issued here and are back long before a cell is reported
     ShardColumns own;
     own.rare = rare_args();
@@ -651,31 +699,24 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
             s = now;
             write_score_lane(nxt, s, l, r);
         } while (lanes);
-#ifdef HAVAC_EXPERIMENT_NO_RECHECK
-        break;
-#endif
         uint32_t marked = 0;
 #pragma unroll
         for (int i = 0; i < kRegs; i++) marked |= nxt[i];
         lanes = __ballot((marked & kCrossedBits) != 0);
     } while (lanes);
-#ifdef HAVAC_SLOW_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef HAVAC_EXPERIMENT_TIME_SLOW
-    if (__lane_id() == 0) { sink.lds->dbg[0] += (unsigned long long)(clock64() - t_in); sink.lds->dbg[1] += 1ull; }
-#endif
 }
 
 // Steps 4Q .. 4Q+3 of the chunk.  `cur` is left untouched (the first add is not in place) and holds the scores the window
 // started from; `nxt` receives the scores after the four steps; the next window swaps the two sets.  One hit test at
 // the end where ssv_chunk_flags says that is exact (`safe`, wave-uniform), else one more in the middle.
-template <int Q, int... I>
+template <bool Trace, int Q, int... I>
 __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
                                             uint32_t safe, const HitSink& sink, uint32_t& staged, uint32_t step0,
-                                            int64_t wave_diag0, std::integer_sequence<int, I...> regs) {
+                                            int64_t wave_diag0, uint32_t table_base, std::integer_sequence<int, I...> regs) {
     static_assert(sizeof...(I) == kRegs, "one index per score register");
     constexpr int H = kRegs / 2;            // match words are read for eight registers at a time: 16 VGPRs in flight, not 32
+    TraceWindow win{};
+    if constexpr (Trace) win = trace_window();
     // steps 4Q, 4Q+1
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -684,11 +725,25 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
 #pragma unroll
         for (int i = 0; i < H; i++) m[i] = match_words<2 * Q>(C[2 * Q + h * H + i]);
         __builtin_amdgcn_sched_barrier(0);      // all eight reads in flight before the first add waits (hipcc otherwise staggers them)
-        HAVAC_GROUP_WAIT
 #pragma unroll
         for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(nxt[h * H + i]) : "v"(cur[h * H + i]), "v"(m[i].x));
+        if constexpr (Trace) {
+#pragma unroll
+            for (int i = 0; i < H; i++)
+                trace_step<false>(win, h * H + i, step0 + 4 * Q, wave_diag0, cur[h * H + i], m[i].x, nxt[h * H + i], C[2 * Q + h * H + i], table_base);
+        }
+        uint32_t mid[H];
+        if constexpr (Trace) {
+#pragma unroll
+            for (int i = 0; i < H; i++) mid[i] = nxt[h * H + i];
+        }
 #pragma unroll
         for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[h * H + i]) : "v"(m[i].y));
+        if constexpr (Trace) {
+#pragma unroll
+            for (int i = 0; i < H; i++)
+                trace_step<true>(win, h * H + i, step0 + 4 * Q + 1, wave_diag0, mid[i], m[i].y, nxt[h * H + i], C[2 * Q + h * H + i], table_base);
+        }
     }
     if (!fresh_uniform(safe)) {
         uint32_t any = 0;
@@ -705,11 +760,27 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
 #pragma unroll
         for (int i = 0; i < H; i++) m[i] = match_words<2 * Q + 1>(C[2 * Q + 1 + h * H + i]);
         __builtin_amdgcn_sched_barrier(0);
-        HAVAC_GROUP_WAIT
+        uint32_t mid[H];
+        if constexpr (Trace) {
+#pragma unroll
+            for (int i = 0; i < H; i++) mid[i] = nxt[h * H + i];
+        }
 #pragma unroll
         for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[h * H + i]) : "v"(m[i].x));
+        if constexpr (Trace) {
+#pragma unroll
+            for (int i = 0; i < H; i++) {
+                trace_step<false>(win, h * H + i, step0 + 4 * Q + 2, wave_diag0, mid[i], m[i].x, nxt[h * H + i], C[2 * Q + 1 + h * H + i], table_base);
+                mid[i] = nxt[h * H + i];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[h * H + i]) : "v"(m[i].y));
+        if constexpr (Trace) {
+#pragma unroll
+            for (int i = 0; i < H; i++)
+                trace_step<true>(win, h * H + i, step0 + 4 * Q + 3, wave_diag0, mid[i], m[i].y, nxt[h * H + i], C[2 * Q + 1 + h * H + i], table_base);
+        }
     }
     uint32_t any = 0;
 #pragma unroll
@@ -720,11 +791,13 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
 
 // ONE step with the tables of step pair 0 (the step behind the model's last chunk: the high cells run one row behind
 // and still owe the last row; the low cells add a padding row, which scores 0).
-template <int... I>
+template <bool Trace, int... I>
 __device__ __forceinline__ void step_last(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
                                           const HitSink& sink, uint32_t& staged, uint32_t step0, int64_t wave_diag0,
-                                          std::integer_sequence<int, I...> regs) {
+                                          uint32_t table_base, std::integer_sequence<int, I...> regs) {
     constexpr int H = kRegs / 2;
+    TraceWindow win{};
+    if constexpr (Trace) win = trace_window();
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         u32x2 m[H];
@@ -734,6 +807,11 @@ __device__ __forceinline__ void step_last(const uint32_t (&cur)[kRegs], uint32_t
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(nxt[h * H + i]) : "v"(cur[h * H + i]), "v"(m[i].x));
+        if constexpr (Trace) {
+#pragma unroll
+            for (int i = 0; i < H; i++)
+                trace_step<false>(win, h * H + i, step0, wave_diag0, cur[h * H + i], m[i].x, nxt[h * H + i], C[h * H + i], table_base);
+        }
     }
     uint32_t any = 0;
 #pragma unroll
@@ -743,14 +821,14 @@ __device__ __forceinline__ void step_last(const uint32_t (&cur)[kRegs], uint32_t
 }
 
 // windows 0 .. N-1 of a chunk; the scores are in `a` on entry and, N being even, in `a` again on exit
-template <int... Q>
+template <bool Trace, int... Q>
 __device__ __forceinline__ void step_windows(uint32_t (&a)[kRegs], uint32_t (&b)[kRegs], uint32_t (&C)[32],
                                              const LazySymbols& z, uint32_t safe, const HitSink& sink, uint32_t& staged,
                                              uint32_t step0, int64_t wave_diag0, std::integer_sequence<int, Q...>) {
     static_assert(sizeof...(Q) % 2 == 0 && sizeof...(Q) * kWindowSteps == kChunkRows, "a whole chunk, an even number of windows");
     ((expand_for_window<Q>(C, z),
-      (Q % 2 == 0 ? step_window<Q>(a, b, C, safe, sink, staged, step0, wave_diag0, std::make_integer_sequence<int, kRegs>{})
-                  : step_window<Q>(b, a, C, safe, sink, staged, step0, wave_diag0, std::make_integer_sequence<int, kRegs>{}))), ...);
+      (Q % 2 == 0 ? step_window<Trace, Q>(a, b, C, safe, sink, staged, step0, wave_diag0, z.table_base, std::make_integer_sequence<int, kRegs>{})
+                  : step_window<Trace, Q>(b, a, C, safe, sink, staged, step0, wave_diag0, z.table_base, std::make_integer_sequence<int, kRegs>{}))), ...);
     expand_entry<15>(C, z);      // entry 31: entry 15 of the next chunk
 }
 
@@ -775,11 +853,10 @@ constexpr uint64_t kSplitBelowRounds = 64; // tall tiles are split by rows when 
 constexpr uint32_t kHandoffSpins = 1u << 26;   // x ~1 us: a minute, far beyond any row block (dense-hit models take ~1 s each)
 
 // 5 waves per SIMD: 96 VGPRs.  cur 16 + nxt 16 + 32 match words in flight + ~19 window addresses + 4 prepared symbol words.
-__global__ __launch_bounds__(64 * kWavesPerBlock, 5)
-void ssv_diag_kernel(const SsvRare /* read through rare_args(), never by name */,
-                     const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
-                     const uint32_t* __restrict__ safe_chunks /* null with a separator mask: every chunk then tests every two steps */,
-                     const int64_t nsymbols, const uint32_t nrows_padded) {
+template <bool Trace>
+__device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
+                                              const uint32_t* __restrict__ safe_chunks, const int64_t nsymbols,
+                                              const uint32_t nrows_padded) {
     __shared__ WaveLds wave_lds[kWavesPerBlock];
 
     const uint32_t lane = threadIdx.x & 63;
@@ -949,7 +1026,7 @@ void ssv_diag_kernel(const SsvRare /* read through rare_args(), never by name */
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
             const uint32_t safe = opaque_uniform((safe_now >> ((p0 >> 5) & 31u)) & 1u);
-            step_windows(x, x2, C, z, safe, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
+            step_windows<Trace>(x, x2, C, z, safe, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
             asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the windows
             next_rows = fetch_rows(p0 + kChunkRows);              // rows[] has kModelSlack words behind the model
             fetch_symbols(p0 + kChunkRows + 32, z);
@@ -960,7 +1037,7 @@ void ssv_diag_kernel(const SsvRare /* read through rare_args(), never by name */
             build_tables(next_rows);                               // fetched for p_end by the last chunk
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-            step_last(x, x2, C, sink, staged, p_end, d0, std::make_integer_sequence<int, kRegs>{});
+            step_last<Trace>(x, x2, C, sink, staged, p_end, d0, table_base, std::make_integer_sequence<int, kRegs>{});
         } else if (p_end < p_hi) {
             // the tile goes on in the next row block: hand the scores over (release: the stores, then the count)
             const rare_args_t rare = rare_args();
@@ -991,10 +1068,6 @@ void ssv_diag_kernel(const SsvRare /* read through rare_args(), never by name */
     // Short models (host: tiles_per_item > 1): a tile of one or two chunks is mostly prologue, and every block that found a
     // hit ends with a returning atomic on the one counter word, which sustains ~90 of them per microsecond chip-wide --
     // at 100 Mbp x 32 rows the blocks ask for more than that.  A wave therefore walks several adjacent tiles.
-#ifdef HAVAC_EXPERIMENT_TIME_SLOW
-    const long long t_item = clock64();
-    if (__lane_id() == 0) lds->dbg[0] = lds->dbg[1] = 0;
-#endif
     if (item < rare_args()->nitems) {
         const uint32_t per_item = split_rows ? 1u : rare_args()->tiles_per_item;
         for (uint32_t g = 0; g < per_item; g++) {
@@ -1003,12 +1076,6 @@ void ssv_diag_kernel(const SsvRare /* read through rare_args(), never by name */
             if (!run_item(unit)) break;
         }
     }
-#ifdef HAVAC_EXPERIMENT_TIME_SLOW
-    if (__lane_id() == 0) { atomicAdd(&g_item_cycles, (unsigned long long)(clock64() - t_item)); atomicAdd(&g_items, 1ull);
-                            atomicAdd(&g_slow_cycles, lds->dbg[0]); atomicAdd(&g_slow_calls, lds->dbg[1]); }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
-        printf("slow path: %llu calls %llu cycles | items %llu cycles %llu\n", g_slow_calls, g_slow_cycles, g_items, g_item_cycles);
-#endif
 
     // What is still staged goes out with ONE returning atomic per block, not per wave: the single counter word
     // sustains ~90 returning atomics per microsecond chip-wide.
@@ -1033,6 +1100,21 @@ void ssv_diag_kernel(const SsvRare /* read through rare_args(), never by name */
         for (uint32_t i = lane_again; i < staged; i += 64)
             if (base + i < capacity) hits[base + i] = staged_to_key(lds->stage[i], row_bits);
     }
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock, 5)
+void ssv_diag_kernel(const SsvRare /* read through rare_args(), never by name */,
+                     const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
+                     const uint32_t* __restrict__ safe_chunks /* null with a separator mask: every chunk then tests every two steps */,
+                     const int64_t nsymbols, const uint32_t nrows_padded) {
+    ssv_diag_body<false>(seq, rows, safe_chunks, nsymbols, nrows_padded);
+}
+
+// the same body with the per-cell trace compiled in (see CellRecord): a debugging aid, never launched unless a trace window is set
+__global__ __launch_bounds__(64 * kWavesPerBlock)
+void ssv_diag_kernel_traced(const SsvRare, const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
+                            const uint32_t* __restrict__ safe_chunks, const int64_t nsymbols, const uint32_t nrows_padded) {
+    ssv_diag_body<true>(seq, rows, safe_chunks, nsymbols, nrows_padded);
 }
 
 // ---------------------------------------------------------------------------

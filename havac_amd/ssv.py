@@ -41,6 +41,11 @@ class SsvContext:
         """the HIP stream finish() orders the records on (0 = the stream of the enqueue)"""
         self._check(self._L.havac_ssv_set_order_stream(self._h, stream or None))
 
+    def set_cell_trace(self, d_cells: int = 0, row0: int = 0, col0: int = 0, nrows: int = 0, ncols: int = 0):
+        """per-cell trace window of the next passes (include/havac_dev.h, havac_cell_record: nrows * ncols records of
+        8 bytes at device address d_cells, cleared by the caller); d_cells = 0 switches it off"""
+        self._check(self._L.havac_ssv_set_cell_trace(self._h, d_cells or None, row0, col0, nrows, ncols))
+
     def finish(self) -> int:
         n = C.c_uint64(0)
         self._check(self._L.havac_ssv_finish(self._h, C.byref(n)))

@@ -230,6 +230,27 @@ int havac_ssv_set_separator_mask(havac_ssv_ctx *ctx, const uint8_t *d_pair_bitma
  * No counterpart in the reference (one run at a time, host/HavacHwClient.cpp:150-170). */
 int havac_ssv_set_order_stream(havac_ssv_ctx *ctx, void *hip_stream);
 
+/* Per-cell trace: the counterpart of the reference's HAVAC_PER_CELL_DATA_TESTING build (device/PublicDefines.h:11,
+ * device/HavacHls.cpp:388-399: every cell processor records prevValue, matchScore, cellValue, symbol, passesThreshold;
+ * test/byCellComparator/byCellComparator.cpp:47-96 compares them with softSsv's).  While a trace window is set, passes
+ * run a second instantiation of the SAME kernel body that writes one record per cell of rows [row0, row0 + nrows) x
+ * columns [col0, col0 + ncols) into d_cells (nrows * ncols records, row-major, cleared by the caller; `written` tells
+ * which cells the kernel visited).  A cell below a crossing on the same diagonal and inside the same four-step window
+ * has `pending` set and no score: the kernel puts crossed cells back to 0 at the window's hit test, not before.
+ * The hit list of such a pass is the usual one.  d_cells = NULL switches the trace off (the default). */
+typedef struct havac_cell_record {
+    uint8_t prev;      /* score of the diagonal's previous cell */
+    int8_t match;      /* match score added */
+    uint8_t score;     /* score afterwards; 0 after a crossing (device/HavacHls.cpp:384) */
+    uint8_t hit;       /* passesThreshold */
+    uint8_t symbol;    /* 0..3; 0xff under a separator (boundary mode) */
+    uint8_t pending;   /* see above */
+    uint8_t zero;
+    uint8_t written;   /* 1 */
+} havac_cell_record;
+int havac_ssv_set_cell_trace(havac_ssv_ctx *ctx, havac_cell_record *d_cells, uint32_t row0, uint64_t col0,
+                             uint32_t nrows, uint32_t ncols);
+
 /* Completes the enqueued pass: waits for it, puts the shard's records in
  * d_hits into device order (radix sort on the enqueue's stream, or on the
  * ordering stream set above) and returns the

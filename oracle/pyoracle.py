@@ -61,6 +61,8 @@ def lib():
         L.havac_oracle_ssv_mt.argtypes = [_u8p, C.c_uint64, _i8p, C.c_uint64, _u64p, C.c_uint64, C.c_int]
         L.havac_oracle_ssv_fast.restype = C.c_int64
         L.havac_oracle_ssv_fast.argtypes = [_u8p, C.c_uint64, _i8p, C.c_uint64, _u64p, C.c_uint64, C.c_int]
+        L.havac_oracle_cells.restype = C.c_int
+        L.havac_oracle_cells.argtypes = [_u8p, C.c_uint64, _i8p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _u8p]
         L.havac_oracle_sort_device_order.argtypes = [_u64p, C.c_uint64]
         L.havac_oracle_sort_row_major.argtypes = [_u64p, C.c_uint64]
         _lib = L
@@ -149,6 +151,21 @@ def ssv(symbols, model, cap=None) -> np.ndarray:
 def ssv_window(symbols, model, col_begin, col_end, cap=None) -> np.ndarray:
     hits = _run(lib().havac_oracle_ssv_window, symbols, model, (int(col_begin), int(col_end)), cap=cap)
     return device_order(hits)
+
+
+CELL_RECORD = np.dtype([("prev", np.uint8), ("match", np.int8), ("score", np.uint8), ("hit", np.uint8), ("symbol", np.uint8),
+                        ("pending", np.uint8), ("zero", np.uint8), ("written", np.uint8)])      # include/havac_dev.h, havac_cell_record
+
+
+def cells(symbols, model, row0, col0, h, w) -> np.ndarray:
+    """per-cell records of rows [row0, row0+h) x columns [col0, col0+w) -> array [h, w] of CELL_RECORD"""
+    symbols = np.ascontiguousarray(symbols, dtype=np.uint8)
+    model = np.ascontiguousarray(model, dtype=np.int8).reshape(-1)
+    out = np.zeros(h * w * 8, dtype=np.uint8)
+    rc = lib().havac_oracle_cells(symbols, symbols.size, model, model.size // 4, row0, col0, h, w, out)
+    if rc != 0:
+        raise ValueError(f"havac_oracle_cells: {rc}")
+    return out.view(CELL_RECORD).reshape(h, w)
 
 
 def ssv_mt(symbols, model, nthreads=0, cap=None) -> np.ndarray:

@@ -333,3 +333,35 @@ int64_t havac_oracle_ssv_fast(const uint8_t *symbols, uint64_t n, const int8_t *
     return havac_oracle_ssv_mt(symbols, n, model, nrows, hits, cap, nthreads);
 }
 #endif
+
+/* ---- per-cell records -------------------------------------------------- */
+
+/* What test/softSsv/SoftSsv.cpp:59-65 records per cell in a HAVAC_PER_CELL_DATA_TESTING build (prevValue, matchScore,
+ * cellValue, symbol, passesThreshold), for the cells of rows [row0, row0 + h) x columns [col0, col0 + w), in the 8-byte
+ * layout of include/havac_dev.h (havac_cell_record; `pending` is always 0 here).  out: h * w records, row-major.
+ * The whole matrix above the window is swept (rows outer, columns inner, as in sweep()). */
+int havac_oracle_cells(const uint8_t *symbols, uint64_t n, const int8_t *model, uint64_t nrows,
+                       uint64_t row0, uint64_t col0, uint64_t h, uint64_t w, uint8_t *out) {
+    if (row0 + h > nrows || col0 + w > n) return -2;
+    uint8_t *row = (uint8_t *)calloc((size_t)n, 1);
+    if (!row) return -1;
+    for (uint64_t p = 0; p < row0 + h; p++) {
+        const int8_t *scores = model + 4 * p;
+        uint8_t upper_left = 0;
+        for (uint64_t s = 0; s < n; s++) {
+            uint8_t above = row[s];
+            int hit = 0;
+            int8_t match = scores[symbols[s]];
+            uint8_t v = havac_oracle_cell(upper_left, match, &hit);
+            if (p >= row0 && s >= col0 && s < col0 + w) {
+                uint8_t *rec = out + 8 * ((p - row0) * w + (s - col0));
+                rec[0] = upper_left; rec[1] = (uint8_t)match; rec[2] = v; rec[3] = (uint8_t)hit;
+                rec[4] = symbols[s]; rec[5] = 0; rec[6] = 0; rec[7] = 1;
+            }
+            upper_left = above;
+            row[s] = v;
+        }
+    }
+    free(row);
+    return 0;
+}

@@ -92,6 +92,12 @@ void havac_oracle_sort_device_order(uint64_t *hits, uint64_t count);
 /* Sort packed records by (row, column): the order the test comparisons use. */
 void havac_oracle_sort_row_major(uint64_t *hits, uint64_t count);
 
+/* Per-cell records of rows [row0, row0 + h) x columns [col0, col0 + w): what test/softSsv/SoftSsv.cpp:59-65 records in a
+ * HAVAC_PER_CELL_DATA_TESTING build, in the 8-byte layout of include/havac_dev.h (havac_cell_record).  out: h * w * 8
+ * bytes, row-major.  0, or negative on a bad window / failed allocation. */
+int havac_oracle_cells(const uint8_t *symbols, uint64_t n, const int8_t *model, uint64_t nrows,
+                       uint64_t row0, uint64_t col0, uint64_t h, uint64_t w, uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

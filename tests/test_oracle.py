@@ -125,3 +125,27 @@ def test_fast_route_equals_plain_sweep(oracle):
         model = np.full((40, 4), 127, np.int8)
         sym = rng.integers(0, 4, size=30_000, dtype=np.uint8)
         assert np.array_equal(oracle.ssv_fast(sym, model), oracle.ssv_reference(sym, model))
+
+
+def test_cell_records_follow_the_recurrence(oracle):
+    """oracle.cells (the checker of the per-cell trace, test/softSsv/SoftSsv.cpp:59-65): every record is one application of
+    the single-cell rule to the record above-left of it, and its crossings are exactly the hit list's"""
+    from havac_amd import synth
+    model, cons = synth.dfam_like_model(90, 31)
+    sym = synth.random_symbols(4000, 32)
+    synth.plant_homologs(sym, cons, sym.size, every=600, length=80, sub=0.05)
+    row0, col0, h, w = 10, 100, 80, 700
+    cells = oracle.cells(sym, model, row0, col0, h, w)
+    assert cells["written"].all() and not cells["pending"].any()
+    assert np.array_equal(cells["symbol"], np.broadcast_to(sym[col0:col0 + w], (h, w)))
+    rows = np.arange(row0, row0 + h)[:, None]
+    assert np.array_equal(cells["match"], model[rows, cells["symbol"]])
+    assert np.array_equal(cells["prev"][1:, 1:], cells["score"][:-1, :-1])      # the diagonal's previous cell
+    t = cells["prev"].astype(int) + cells["match"].astype(int)
+    assert np.array_equal(cells["hit"], (t >= 256).astype(np.uint8))
+    assert np.array_equal(cells["score"], np.where((t < 0) | (t >= 256), 0, t).astype(np.uint8))
+    r, c = oracle.unpack_hits(oracle.ssv(sym, model))
+    inside = (r >= row0) & (r < row0 + h) & (c >= col0) & (c < col0 + w)
+    want = np.zeros((h, w), np.uint8)
+    want[(r[inside] - row0).astype(int), (c[inside] - col0).astype(int)] = 1
+    assert np.array_equal(cells["hit"], want)
