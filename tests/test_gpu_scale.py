@@ -308,3 +308,43 @@ def test_passes_in_flight_give_the_same_lists(torch_dev, oracle):
     assert len(got) == 6
     for (_, _, _, _, want), mine in zip(problems, got):
         assert want.size > 0 and np.array_equal(mine, want)
+
+
+@pytest.mark.parametrize("nrows", [32, 64, 100])
+def test_short_models_whole_hit_list(torch_dev, oracle, nrows):
+    """Short single models x 100 Mbp: a wave walks several ADJACENT tiles (tiles_per_item > 1 in the launch, see
+    havac_dev.hip) and what it staged leaves at the end of all of them; the whole hit list against the checker."""
+    torch, dev = torch_dev
+    ncols = 100_012_032
+    model, cons = synth.dfam_like_model(nrows, 4242 + nrows)
+    packed = synth.random_packed(ncols, 4243)
+    got, = run_shards(torch, dev, packed, model)
+    assert got.size > 1000
+    assert np.array_equal(got, whole_list(oracle, packed, model))
+
+
+@pytest.mark.parametrize("per_item", [2, 3, 8])
+def test_tiles_per_item_forced_on_small_problems(torch_dev, oracle, per_item, monkeypatch):
+    """the same path on small, ragged problems (tile counts that are no multiple of the group, one-row models, the
+    matrix's edges inside a group): HAVAC_TILES_PER_ITEM forces the grouping the launch would only choose for big inputs"""
+    torch, dev = torch_dev
+    monkeypatch.setenv("HAVAC_TILES_PER_ITEM", str(per_item))
+    rng = np.random.default_rng(per_item)
+    for case in range(12):
+        nrows = int(rng.choice([1, 2, 31, 32, 33, 64, 100, 128, 300]))
+        nseg = int(rng.integers(1, 8))
+        sym = synth.random_symbols(nseg * synth.SEGMENT, 50 + case)
+        if case % 3 == 0:
+            model = rng.integers(-128, 128, size=(nrows, 4)).astype(np.int8)       # dense hits, two-step windows
+        else:
+            model, cons = synth.dfam_like_model(nrows, 60 + case)
+            synth.plant_homologs(sym, cons, sym.size, every=900, length=min(nrows, 150), sub=0.08)
+        got, = run_shards(torch, dev, synth.pack_2bit(sym), model, capacity=1 << 23)
+        want = oracle.ssv(sym, model, cap=1 << 23)
+        assert np.array_equal(got, want), (per_item, case, nrows, nseg, got.size, want.size)
+    # and sharded: every shard groups its own tiles
+    sym = synth.random_symbols(9 * synth.SEGMENT, 99)
+    model, cons = synth.dfam_like_model(64, 98)
+    synth.plant_homologs(sym, cons, sym.size, every=700, length=60, sub=0.05)
+    parts = run_shards(torch, dev, synth.pack_2bit(sym), model, world=4)
+    assert np.array_equal(np.concatenate(parts), oracle.ssv(sym, model))
