@@ -71,7 +71,16 @@ constexpr int kRegs = kDiagsPerLane / 2;
 constexpr int kTileDiags = 64 * kDiagsPerLane;    // one wave
 constexpr int kChunkRows = 32;                    // steps per unrolled chunk
 constexpr int kChunkPairs = kChunkRows / 2;
-constexpr int kWavesPerBlock = 4;
+#ifndef HAVAC_BATCH
+#define HAVAC_BATCH 8
+#endif
+#ifndef HAVAC_WAVES_PER_SIMD
+#define HAVAC_WAVES_PER_SIMD 6
+#endif
+#ifndef HAVAC_WAVES_PER_BLOCK
+#define HAVAC_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = HAVAC_WAVES_PER_BLOCK;
 constexpr int kModelSlack = 40;                   // padding rows kept behind the padded model (table look-ahead)
 constexpr uint32_t kScoreZero = 0x80008000u;      // two cells at score 0: 256*0 - 32768
 constexpr uint32_t kCrossedBits = 0x00010001u;    // bit 0 of either cell: set only in 0x7fff-derived values
@@ -433,18 +442,40 @@ __device__ __forceinline__ int32_t clamp_to_4096(int64_t v) {
     return hi < 0 ? 0 : ((hi > 0 || lo > 4096u) ? 4096 : (int32_t)lo);
 }
 
+// The lane number, computed where it is needed (three instructions) and opaque to the optimiser, which would otherwise
+// compute it once and keep it -- and what is derived from it -- in VGPRs through the whole kernel.
+__device__ __forceinline__ uint32_t fresh_lane() {
+    uint32_t lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    return lane;
+}
+// What a lane needs once per chunk for the table build and the loads of the next chunk lives in LDS, as four arrays of 64
+// words read with ds_read_addtid_b32 (address = M0 + offset + 4 * lane: no address register either):
+// {selector of its second match word, LDS offset of its four table entries, byte offset of its step pair in a chunk's rows,
+// 8 * lane = byte offset of its 32 symbols in the wave's 512 packed bytes}.
+struct LaneWords { uint32_t sel_second, entries, row_offset, lane8; };
+__device__ __forceinline__ LaneWords read_lane_words(uint32_t lds_address) {
+    LaneWords w;
+    // (s_nop: an SALU write of M0 needs one wait state before an add-TID LDS instruction reads it; nothing inserts it inside an asm)
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "ds_read_addtid_b32 %0 offset:0\n\tds_read_addtid_b32 %1 offset:256\n\t"
+                 "ds_read_addtid_b32 %2 offset:512\n\tds_read_addtid_b32 %3 offset:768\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=v"(w.sel_second), "=v"(w.entries), "=v"(w.row_offset), "=v"(w.lane8) : "s"(lds_address) : "m0", "memory");
+    return w;
+}
+
 // ---- the symbol window, expanded as the windows reach it --------------------------------------------------------
 // A chunk of 32 steps looks at 64 symbols per lane = 32 symbol pairs; C[k] is the LDS address of the table entry of
 // pair k (code * 8 | table base).  Pairs 0..15 are the upper half of the previous chunk's window; pairs 16..31 come from
 // the 8 bytes loaded for this chunk and are expanded entry by entry: window Q (steps 4Q..4Q+3) uses entries 2Q..2Q+16
 // only, so 17 of the 32 addresses (plus the four prepared words) are alive at a time -- the registers that let both
-// score sets stay alive at five waves per SIMD.
+// score sets stay alive at six waves per SIMD.
 struct LazySymbols {
     uint32_t even[2], odd[2];   // per packed word (pairs 16..23, 24..31): code*8 of its even / odd pairs, one per byte
     uint32_t separators;        // bit K: pair 16+K is a separator pair (boundary mode); 0 otherwise
     uint32_t table_base;
     uint32_t special;           // wave-uniform, 0 or 1 (a 32-bit SGPR, not a lane mask): some position of the wave lies outside [0, N), or a separator is present
-    uint32_t lane8;             // 8 * lane; 32 * lane is the lane's first position relative to the wave's (only read when special)
     int32_t valid_lo, valid_hi; // wave-uniform: positions relative to the wave's first that lie inside [0, N): [valid_lo, valid_hi)
 };
 
@@ -470,9 +501,8 @@ __device__ __forceinline__ void expand_entry(uint32_t (&C)[32], const LazySymbol
     uint32_t entry = or_byte<n / 2>(z.table_base, (n & 1) ? z.odd[K / 8] : z.even[K / 8]);
     if (fresh_uniform(z.special)) {
         // positions outside [0, N) and separator pairs use the 17th entry of the tables
-        uint32_t lane32 = z.lane8 * 4;
-        asm volatile("" : "+v"(lane32));                        // computed here, in the rare chunks that need it: hipcc otherwise
-                                                                // hoists the 16 sums below out of the chunk loop and spills them
+        const uint32_t lane32 = fresh_lane() * 32u;           // computed here, in the rare chunks that need it (nothing that
+                                                                // depends on the lane number is kept in a VGPR through the windows)
         const int32_t q = (int32_t)lane32 + 2 * K;              // the pair's positions q and q+1 are in or out together
         if (q < z.valid_lo || q >= z.valid_hi || ((z.separators >> K) & 1u)) entry = z.table_base + kOutsideCode;
     }
@@ -714,12 +744,13 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
                                             uint32_t safe, const HitSink& sink, uint32_t& staged, uint32_t step0,
                                             int64_t wave_diag0, uint32_t table_base, std::integer_sequence<int, I...> regs) {
     static_assert(sizeof...(I) == kRegs, "one index per score register");
-    constexpr int H = kRegs / 2;            // match words are read for eight registers at a time: 16 VGPRs in flight, not 32
+    constexpr int H = HAVAC_BATCH;          // match words are read for eight registers at a time: 16 VGPRs in flight, not 32
+    constexpr int NB = kRegs / H;
     TraceWindow win{};
     if constexpr (Trace) win = trace_window();
     // steps 4Q, 4Q+1
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < NB; h++) {
         u32x2 m[H];
         __builtin_amdgcn_sched_barrier(0);      // reads stay behind the adds before them: hoisted, they cost registers the kernel does not have
 #pragma unroll
@@ -754,7 +785,7 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
     }
     // steps 4Q+2, 4Q+3
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < NB; h++) {
         u32x2 m[H];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -846,13 +877,16 @@ __device__ __forceinline__ uint32_t word_selector(uint32_t a) { return 0x040c000
 // has started, whatever order blocks are dispatched in: the wait always ends.
 constexpr int kTicketStride = 16;          // the ticket counter and the fault word sit in cache lines of their own
 constexpr int kTicketCounters = 1;
-constexpr int kBlocksPerCu = 5;            // 5 blocks of 4 waves = 5 waves per SIMD
+constexpr int kBlocksPerCu = 4 * HAVAC_WAVES_PER_SIMD / kWavesPerBlock;   // 24 waves per CU = 6 waves per SIMD
 constexpr uint32_t kRowsPerBlock = 8192;   // rows of a row block (a multiple of 1024: the chunk-flag words); a hand-off
                                            // moves 2 x 4 KB per 8192 x 2048 cells
 constexpr uint64_t kSplitBelowRounds = 64; // tall tiles are split by rows when there are fewer of them than this many rounds of wave slots
 constexpr uint32_t kHandoffSpins = 1u << 26;   // x ~1 us: a minute, far beyond any row block (dense-hit models take ~1 s each)
 
-// 5 waves per SIMD: 96 VGPRs.  cur 16 + nxt 16 + 32 match words in flight + ~19 window addresses + 4 prepared symbol words.
+// 6 waves per SIMD: 80 VGPRs = cur 16 + nxt 16 + 16 match words in flight + ~19 window addresses + 4 prepared symbol words + a
+// few temporaries.  Nothing else is kept in a VGPR through the windows: no lane number (LaneWords, fresh_lane), no
+// SGPR spills (SsvRare).  The sixth wave is worth 3 % (C2 kernel 1.93 -> 1.87 ms); a seventh (72 VGPRs) needs batches of
+// four match-word pairs and spills in the chunk epilogue.
 template <bool Trace>
 __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
                                               const uint32_t* __restrict__ safe_chunks, const int64_t nsymbols,
@@ -870,12 +904,13 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
     const uint32_t table_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds->table);
     // this lane's share of the table build: the four entries (a, b) with b = lane & 3 of step pair lane >> 2
     const uint32_t my_pair = lane >> 2, my_b = lane & 3;
-    const uint32_t lane8 = lane * 8;            // byte offset of the lane's 32 symbols in the wave's 512 packed bytes
-    // What a lane needs once per chunk for the table build and the model-row fetch lives in LDS, not in three VGPRs
-    // that would be idle through the windows: {selector of its second match word, LDS offset of its four entries,
-    // byte offset of its step pair in a chunk's rows}.  Every wave writes the same values and reads back its own.
-    __shared__ uint4 lane_consts[64];
-    lane_consts[lane] = make_uint4(word_selector(my_b), my_pair * kPairStride + my_b * 32, my_pair * 8, 0u);
+    // (see LaneWords; every wave writes the same values and reads back its own)
+    __shared__ uint32_t lane_words[4][64];
+    lane_words[0][lane] = word_selector(my_b);
+    lane_words[1][lane] = my_pair * kPairStride + my_b * 32;
+    lane_words[2][lane] = my_pair * 8;
+    lane_words[3][lane] = lane * 8;
+    const uint32_t lane_words_address = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&lane_words[0][0]);
     if (my_b == 0) {      // the "outside the matrix" entry of each table never changes
         // Without separators it scores 0: a cell outside the matrix keeps what it has (0 before a diagonal enters at
         // column 0; behind the last column nothing is reported any more) and a mark is never lost there.  With a
@@ -935,13 +970,14 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
                     if (__hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
                 }
                 if (spins == kHandoffSpins) {
-                    if (lane8 == 0) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (fresh_lane() == 0) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     return false;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const uint32_t my_lane = fresh_lane();
 #pragma unroll
-            for (int i = 0; i < kRegs; i++) x[i] = tile_state[i * 64 + (lane8 >> 3)];
+            for (int i = 0; i < kRegs; i++) x[i] = tile_state[i * 64 + my_lane];
         } else {
 #pragma unroll
             for (int i = 0; i < kRegs; i++) x[i] = kScoreZero;
@@ -953,24 +989,19 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         uint32_t C[32];
         // The 32 symbols (8 bytes) of this lane at position d0 + rel + 32 lane, rel wave-uniform, ready for expansion;
         // the wave's 512 bytes are consecutive: a uniform base and the lane's byte offset.
-        auto fetch_symbols = [&](int64_t rel, LazySymbols& z) {
+        auto fetch_symbols = [&](int64_t rel, LazySymbols& z, const uint32_t lane8) {
             const int64_t first = d0 + rel;                               // the wave's first position
             // positions relative to `first` that lie inside [0, N), clamped to [0, 4096]: all of it on the scalar unit
             z.valid_lo = clamp_to_4096(-first);
             z.valid_hi = clamp_to_4096(nsymbols - first);
             const uint32_t edge = (uint32_t)(z.valid_lo != 0) | (uint32_t)(z.valid_hi < kTileDiags);   // first < 0, or first + 2048 > N
             const uint8_t* const base = seq + (first >> 2);             // only dereferenced for lanes inside [0, N)
-            z.lane8 = lane8;
             z.table_base = table_base;
             uint2 w = make_uint2(0u, 0u);
             z.separators = 0;
             if (!edge) {                                                  // the usual case: one coalesced load, uniform base + lane offset
-                // (the offset is made opaque HERE so that its zero-extension is in this block, where instruction selection
-                // can fold it into the load's "SGPR base + 32-bit VGPR offset" form; hoisted out of the chunk loop it is a 64-bit
-                // VGPR pair and costs a v_lshl_add_u64 per load)
-                uint32_t offset = lane8;
-                asm volatile("" : "+v"(offset));
-                w = *reinterpret_cast<const uint2*>(base + offset);
+                // (lane8 comes fresh from LDS in this block: its zero-extension folds into the load's "SGPR base + 32-bit VGPR offset" form)
+                w = *reinterpret_cast<const uint2*>(base + lane8);
                 if (!safe_chunks) z.separators = rare_args()->pair_mask[(first >> 5) + (lane8 >> 3)];
             } else if ((int32_t)(lane8 * 4) >= z.valid_lo && (int32_t)(lane8 * 4) + 32 <= z.valid_hi) {
                 w = *reinterpret_cast<const uint2*>(base + lane8);
@@ -985,10 +1016,9 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         // word(t, a) = (M[t][a] << 8) | (M[t-1][a] << 24); rows[] is shifted by one, so rows[t] is M[t-1].
         // Four lanes share a step pair: they fetch its three model rows and each writes the entries of one b.
         struct ModelRows { uint32_t r0, r1, r2, sel_second, entries; };
-        auto fetch_rows = [&](uint32_t p0) -> ModelRows {
-            const uint4 mine = lane_consts[lane8 >> 3];
-            const uint32_t* r = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(rows + p0) + mine.z);
-            return ModelRows{r[0], r[1], r[2], mine.x, mine.y};
+        auto fetch_rows = [&](uint32_t p0, const LaneWords& mine) -> ModelRows {
+            const uint32_t* r = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(rows + p0) + mine.row_offset);
+            return ModelRows{r[0], r[1], r[2], mine.sel_second, mine.entries};
         };
         auto build_tables = [&](const ModelRows r) {
             const uint32_t second = __builtin_amdgcn_perm(r.r1, r.r2, r.sel_second);
@@ -997,14 +1027,15 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             for (int a = 0; a < 4; a++) out[a] = u32x2{__builtin_amdgcn_perm(r.r0, r.r1, word_selector(a)), second};
         };
         LazySymbols z;
-        fetch_symbols(p_begin, z);
+        LaneWords mine = read_lane_words(lane_words_address);
+        fetch_symbols(p_begin, z, mine.lane8);
         expand_all(C, z, std::make_integer_sequence<int, 16>{});       // -> C[16..32): the first chunk's lower half after the slide
         // The global loads of a chunk (12 B of model rows and 8 B of symbols per lane) are issued at the END of the chunk
         // before it and consumed at its top: no register carries them across the windows, and the latency that is
         // exposed this way is covered by the other four waves of the SIMD (measured in round 1: 2.12 ms against 2.16 ms
         // with the loads issued a whole chunk ahead).
-        ModelRows next_rows = fetch_rows(p_begin);
-        fetch_symbols(p_begin + 32, z);
+        ModelRows next_rows = fetch_rows(p_begin, mine);
+        fetch_symbols(p_begin + 32, z, mine.lane8);
 
         bool go_on = true;                 // wave-uniform
         // one bit per chunk: may the chunk look for hits every four steps only (ssv_chunk_flags)?  never with separators.
@@ -1028,8 +1059,9 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             const uint32_t safe = opaque_uniform((safe_now >> ((p0 >> 5) & 31u)) & 1u);
             step_windows<Trace>(x, x2, C, z, safe, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
             asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the windows
-            next_rows = fetch_rows(p0 + kChunkRows);              // rows[] has kModelSlack words behind the model
-            fetch_symbols(p0 + kChunkRows + 32, z);
+            mine = read_lane_words(lane_words_address);
+            next_rows = fetch_rows(p0 + kChunkRows, mine);        // rows[] has kModelSlack words behind the model
+            fetch_symbols(p0 + kChunkRows + 32, z, mine.lane8);
         }
         if (!go_on) return false;
         if (p_end == nrows_padded) {
@@ -1042,10 +1074,11 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             // the tile goes on in the next row block: hand the scores over (release: the stores, then the count)
             const rare_args_t rare = rare_args();
             uint32_t* const tile_state = rare->block_state + (size_t)tile_in_launch * (kRegs * 64);
+            const uint32_t my_lane = fresh_lane();
 #pragma unroll
-            for (int i = 0; i < kRegs; i++) tile_state[i * 64 + (lane8 >> 3)] = x[i];
+            for (int i = 0; i < kRegs; i++) tile_state[i * 64 + my_lane] = x[i];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (lane8 == 0) __hip_atomic_store(rare->block_flags + tile_in_launch, block + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (my_lane == 0) __hip_atomic_store(rare->block_flags + tile_in_launch, block + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return true;
     };
@@ -1102,7 +1135,7 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
     }
 }
 
-__global__ __launch_bounds__(64 * kWavesPerBlock, 5)
+__global__ __launch_bounds__(64 * kWavesPerBlock, HAVAC_WAVES_PER_SIMD)
 void ssv_diag_kernel(const SsvRare /* read through rare_args(), never by name */,
                      const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
                      const uint32_t* __restrict__ safe_chunks /* null with a separator mask: every chunk then tests every two steps */,

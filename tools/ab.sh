@@ -11,7 +11,7 @@ for round in 1 2; do
   for v in $variants; do
     cp build/ab/lib$v.so havac_amd/libhavac_dev.so
     echo "== $v" >> gpurun_out/ab.log
-    timeout -k 10 200 python tools/hit_density_probe.py 2>/dev/null | tail -3 >> gpurun_out/ab.log
+    timeout -k 10 60 python tools/hit_density_probe.py 2>/dev/null | tail -3 >> gpurun_out/ab.log
   done
 done
 cp build/ab/_kept.so havac_amd/libhavac_dev.so
