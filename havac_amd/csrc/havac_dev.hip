@@ -282,10 +282,10 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     }
     const bool split = rows_per_block != 0;
     // Short models: a wave walks several adjacent tiles (ssv_kernels.hip.h, "items") -- as many as make ~256 rows of work,
-    // at most 8, and never so many that fewer than four rounds of wave slots are left to balance the chip.
+    // at most 8, and never so many that fewer than three rounds of wave slots are left to balance the chip.
     uint32_t tiles_per_item = 1;
     if (!split && te > tb && t.nrows_padded <= 128) {
-        const uint64_t by_rounds = L.ntiles / (4 * slots);
+        const uint64_t by_rounds = L.ntiles / (3 * slots);
         tiles_per_item = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({8, 256 / t.nrows_padded, by_rounds}));
     }
     if (const char* forced = std::getenv("HAVAC_TILES_PER_ITEM")) {           // experiments
