@@ -93,6 +93,7 @@ struct havac_ssv_ctx {
     uint32_t* tickets = nullptr;                                    // kTicketCounters counters + the fault word
     uint32_t* block_flags = nullptr; size_t block_flag_tiles = 0;   // row-split launches: row blocks finished, per tile
     uint32_t* block_state = nullptr; size_t block_state_tiles = 0;  // row-split launches: 16 x 64 scores per tile
+    uint64_t* tails = nullptr; uint32_t* tail_counts = nullptr; size_t tail_blocks = 0;   // block tails (ssv_kernels.hip.h): kTailSlots keys + a count per block
     int resident_blocks = 0;                                        // blocks the device holds at once (5 per CU)
     const uint16_t* pair_mask = nullptr;                // optional separator bitmap (boundary mode), caller-owned
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
@@ -147,6 +148,8 @@ extern "C" void havac_ssv_ctx_destroy(havac_ssv_ctx* c) {
     if (c->tickets) (void)hipFree(c->tickets);
     if (c->block_flags) (void)hipFree(c->block_flags);
     if (c->block_state) (void)hipFree(c->block_state);
+    if (c->tails) (void)hipFree(c->tails);
+    if (c->tail_counts) (void)hipFree(c->tail_counts);
     if (c->sort_tmp) (void)hipFree(c->sort_tmp);
     if (c->sort_alt) (void)hipFree(c->sort_alt);
     if (c->d_count) (void)hipFree(c->d_count);
@@ -281,13 +284,10 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         if (rows_per_block >= t.nrows_padded) rows_per_block = 0;
     }
     const bool split = rows_per_block != 0;
-    // Short models: a wave walks several adjacent tiles (ssv_kernels.hip.h, "items") -- as many as make ~256 rows of work,
-    // at most 8, and never so many that fewer than three rounds of wave slots are left to balance the chip.
+    // A wave can walk several adjacent tiles (ssv_kernels.hip.h, "items"; HAVAC_TILES_PER_ITEM).  Built for short models, whose
+    // blocks queued up at the hit counter; the block tails removed that queue altogether, and with them groups of two
+    // tiles are 1-3 % SLOWER than single tiles (fewer, longer items balance worse): off unless forced.
     uint32_t tiles_per_item = 1;
-    if (!split && te > tb && t.nrows_padded <= 128) {
-        const uint64_t by_rounds = L.ntiles / (3 * slots);
-        tiles_per_item = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({8, 256 / t.nrows_padded, by_rounds}));
-    }
     if (const char* forced = std::getenv("HAVAC_TILES_PER_ITEM")) {           // experiments
         tiles_per_item = (uint32_t)std::max(1, std::atoi(forced));
         if (split) tiles_per_item = 1;
@@ -321,12 +321,29 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         }
     }
     HIP_TRY(c->err, hipEventRecord(c->ev[1], stream));
+    bool tails_in_use = false;
     if (te > tb) {
         SsvRare& R = L;
         R.hits = d_hits; R.hit_count = c->d_count; R.hit_capacity = hit_capacity;
         R.col_begin = (int64_t)col_begin; R.col_span = col_end - col_begin;
         R.abort_flag = d_abort_flag; R.pair_mask = c->pair_mask; R.tickets = c->tickets; R.block_flags = c->block_flags; R.block_state = c->block_state;
         R.fault = c->tickets + kTicketCounters * kTicketStride; R.row_bits = row_bits;
+        // block tails: a side buffer of kTailSlots keys per block, for launches of up to 128 MB of it (C2: 12.5 MB, C3: 81 MB;
+        // C4's per-GPU share has 950,000 blocks and keeps the atomic at a block's end: its blocks live for milliseconds)
+        bool use_tails = (uint64_t)nblocks * kTailSlots * sizeof(uint64_t) <= (128ull << 20);
+        if (const char* forced = std::getenv("HAVAC_BLOCK_TAILS")) use_tails = use_tails && std::atoi(forced) != 0;     // experiments: 0 = off
+        if (use_tails && c->tail_blocks < nblocks) {
+            HIP_TRY(c->err, hipStreamSynchronize(stream));        // an earlier pass on this stream may still use the old buffers
+            if (c->tails) (void)hipFree(c->tails);
+            if (c->tail_counts) (void)hipFree(c->tail_counts);
+            c->tails = nullptr; c->tail_counts = nullptr; c->tail_blocks = 0;
+            const size_t want = (size_t)nblocks + nblocks / 4 + 64;
+            HIP_TRY(c->err, hipMalloc(&c->tails, want * kTailSlots * sizeof(uint64_t)));
+            HIP_TRY(c->err, hipMalloc(&c->tail_counts, want * sizeof(uint32_t)));
+            c->tail_blocks = want;
+        }
+        R.tails = use_tails ? c->tails : nullptr; R.tail_counts = use_tails ? c->tail_counts : nullptr;
+        tails_in_use = use_tails;
         R.cells = c->trace_cells; R.cell_row0 = c->trace_row0; R.cell_col0 = (int64_t)c->trace_col0;
         R.cell_rows = c->trace_rows; R.cell_cols = c->trace_cols;
         const uint32_t* const safe_chunks = c->pair_mask ? (const uint32_t*)nullptr : (const uint32_t*)c->chunk_flags;
@@ -338,10 +355,17 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
                                d_sequence, (const uint32_t*)c->rows8, safe_chunks, (int64_t)nsymbols, t.nrows_padded);
     }
     HIP_TRY(c->err, hipEventRecord(c->ev[2], stream));
-    HIP_TRY(c->err, hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    // What follows the kernel -- the gather of the block tails and the copy of the count -- runs on the ordering stream
+    // when there is one: the kernel stream is then free for the next pass's kernel at once.
+    const hipStream_t after = c->order_stream ? c->order_stream : stream;
+    if (after != stream) HIP_TRY(c->err, hipStreamWaitEvent(after, c->ev[2], 0));
+    if (te > tb && tails_in_use)
+        hipLaunchKernelGGL(ssv_gather_tails, dim3((nblocks + kGatherBlocks - 1) / kGatherBlocks), dim3(256), 0, after, (const uint64_t*)c->tails,
+                           (const uint32_t*)c->tail_counts, nblocks, d_hits, c->d_count, hit_capacity);
+    HIP_TRY(c->err, hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, after));
     // the kernel's fault word (a row-block hand-off that never came): never expected, but never waited for silently either
-    HIP_TRY(c->err, hipMemcpyAsync(c->h_count + 1, c->tickets + kTicketCounters * kTicketStride, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(c->err, hipEventRecord(c->ev[4], stream));       // finish() waits for THIS, not for the stream: later passes may be queued behind it
+    HIP_TRY(c->err, hipMemcpyAsync(c->h_count + 1, c->tickets + kTicketCounters * kTicketStride, sizeof(uint32_t), hipMemcpyDeviceToHost, after));
+    HIP_TRY(c->err, hipEventRecord(c->ev[4], after));       // finish() waits for THIS, not for the stream: later passes may be queued behind it
     HIP_TRY(c->err, hipGetLastError());
     c->pending = true; c->stream = stream; c->d_hits = d_hits; c->hit_capacity = hit_capacity;
     c->row_bits = row_bits;

@@ -94,6 +94,7 @@ constexpr int kPairStride = 17 * 8;               // 16 symbol-pair codes + the 
 constexpr uint32_t kOutsideCode = 16 * 8;         // byte offset of that entry
 constexpr int kTableBytes = 2304;                 // 16 x 136 = 2176, rounded up to a multiple of 128
 constexpr int kHitStage = 128;                    // records staged per wave (1 KiB)
+constexpr int kTailSlots = 128;                   // records a block may leave in its slots of the side buffer when it ends (block tails)
 
 // sort key of a hit: (segment, row, column-in-segment) -- the FPGA's emission
 // order (device/HavacHls.cpp:151-152,264; device/HitReporting.cpp:178-337)
@@ -341,6 +342,8 @@ struct SsvRare {
     uint32_t rows_per_block;       // 0: tiles are not split by rows (an item is a tile); else a multiple of 1024
     uint32_t tiles_per_item;       // >= 1; > 1 only for short models (rows_per_block == 0): a wave walks that many ADJACENT tiles,
                                    // and what it staged leaves with one atomic per block at the end of all of them
+    // side buffer for what a block still has staged when it ends (see "block tails"); tails == nullptr: the atomic path
+    uint64_t* tails; uint32_t* tail_counts;
     // per-cell trace (ssv_diag_kernel_traced only): one CellRecord per cell of rows [cell_row0, +cell_rows) x columns [cell_col0, +cell_cols)
     struct CellRecord* cells; int64_t cell_col0; uint32_t cell_row0, cell_rows, cell_cols;
 };
@@ -1110,28 +1113,89 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         }
     }
 
-    // What is still staged goes out with ONE returning atomic per block, not per wave: the single counter word
-    // sustains ~90 returning atomics per microsecond chip-wide.
+    // ---- block tails ----------------------------------------------------------------------------------------------------
+    // What is still staged when the block ends.  A returning atomic on the one counter word is the obvious way out, and
+    // for short models the wrong one: the word sustains ~90 returning atomics per microsecond chip-wide, a launch of
+    // one-chunk tiles ends 100+ blocks per microsecond, and every one of them waits ~2 us for its answer.  So the block
+    // writes its tail -- up to kTailSlots records -- with plain stores into ITS OWN slots of a side buffer, notes the count
+    // and is gone; ssv_gather_tails, a small kernel behind this one, moves the tails into the queue with one atomic per
+    // 256 blocks.  A tail that does not fit (or a launch too big for a side buffer) takes the atomic, once per block.
     __shared__ uint32_t block_staged[kWavesPerBlock];
     __shared__ unsigned long long block_base;
     const uint32_t lane_again = __lane_id();     // not kept through the items: two instructions here
     if (lane_again == 0) block_staged[wave] = staged;
     __syncthreads();
+    uint32_t total = 0, before_me = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; w++) { total += block_staged[w]; before_me += (uint32_t)w < wave ? block_staged[w] : 0u; }
+    const rare_args_t rare = rare_args();
+    uint64_t* const tails = rare->tails;
+    if (tails && total <= (uint32_t)kTailSlots) {
+        if (threadIdx.x == 0) rare->tail_counts[blockIdx.x] = total;
+        if (staged) {
+            const uint32_t row_bits = rare->row_bits;
+            uint64_t* const mine = tails + (size_t)blockIdx.x * kTailSlots + before_me;
+            for (uint32_t i = lane_again; i < staged; i += 64) mine[i] = staged_to_key(lds->stage[i], row_bits);
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (int w = 0; w < kWavesPerBlock; w++) total += block_staged[w];
-        block_base = total ? atomicAdd(rare_args()->hit_count, (unsigned long long)total) : 0ull;
+        if (tails) rare->tail_counts[blockIdx.x] = 0;
+        block_base = total ? atomicAdd(rare->hit_count, (unsigned long long)total) : 0ull;
     }
     __syncthreads();
     if (staged) {
-        const rare_args_t rare = rare_args();
         uint64_t* const hits = rare->hits;
         const uint64_t capacity = rare->hit_capacity;
         const uint32_t row_bits = rare->row_bits;
-        unsigned long long base = block_base;
-        for (uint32_t w = 0; w < wave; w++) base += block_staged[w];
+        const unsigned long long base = block_base + before_me;
         for (uint32_t i = lane_again; i < staged; i += 64)
             if (base + i < capacity) hits[base + i] = staged_to_key(lds->stage[i], row_bits);
+    }
+}
+
+// The tails of `nblocks` blocks (tail_counts[b] sort keys at tails[b * kTailSlots ...]) are appended to the queue.  A
+// workgroup takes kGatherBlocks tails: one lane per tail sums the counts up (a scan over a wave), ONE returning atomic
+// reserves the workgroup's stretch of the queue, and each of the four waves copies its share of the tails with all its
+// loads in flight before the first store (a tail is at most two keys per lane).
+constexpr int kGatherBlocks = 32;
+__global__ __launch_bounds__(256)
+void ssv_gather_tails(const uint64_t* __restrict__ tails, const uint32_t* __restrict__ tail_counts, uint32_t nblocks,
+                      uint64_t* __restrict__ hits, unsigned long long* hit_count, uint64_t capacity) {
+    static_assert(kTailSlots == 128 && kGatherBlocks == 32, "two keys per lane and tail, eight tails per wave");
+    __shared__ uint32_t count[kGatherBlocks], offset[kGatherBlocks];
+    __shared__ unsigned long long base;
+    const uint32_t first = blockIdx.x * kGatherBlocks;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) {
+        const uint32_t n = (lane < (uint32_t)kGatherBlocks && first + lane < nblocks) ? tail_counts[first + lane] : 0u;
+        uint32_t inclusive = n;
+#pragma unroll
+        for (int d = 1; d < kGatherBlocks; d *= 2) {
+            const uint32_t up = __shfl_up(inclusive, d, 64);
+            if ((int)lane >= d) inclusive += up;
+        }
+        if (lane < (uint32_t)kGatherBlocks) { count[lane] = n; offset[lane] = inclusive - n; }
+        if (lane == kGatherBlocks - 1) base = inclusive ? atomicAdd(hit_count, (unsigned long long)inclusive) : 0ull;
+    }
+    __syncthreads();
+    constexpr int kPerWave = kGatherBlocks / 4;
+    uint64_t key[kPerWave][2];
+#pragma unroll
+    for (int k = 0; k < kPerWave; k++) {
+        const uint32_t r = wave * kPerWave + k;
+        const uint64_t* const src = tails + (size_t)(first + r) * kTailSlots;
+        const uint32_t n = count[r];
+        key[k][0] = lane < n ? src[lane] : 0;
+        key[k][1] = lane + 64 < n ? src[lane + 64] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kPerWave; k++) {
+        const uint32_t r = wave * kPerWave + k;
+        const uint32_t n = count[r];
+        const unsigned long long dst = base + offset[r];
+        if (lane < n && dst + lane < capacity) hits[dst + lane] = key[k][0];
+        if (lane + 64 < n && dst + lane + 64 < capacity) hits[dst + lane + 64] = key[k][1];
     }
 }
 

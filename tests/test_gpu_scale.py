@@ -348,3 +348,31 @@ def test_tiles_per_item_forced_on_small_problems(torch_dev, oracle, per_item, mo
     synth.plant_homologs(sym, cons, sym.size, every=700, length=60, sub=0.05)
     parts = run_shards(torch, dev, synth.pack_2bit(sym), model, world=4)
     assert np.array_equal(np.concatenate(parts), oracle.ssv(sym, model))
+
+
+@pytest.mark.parametrize("tails", ["0", "1"])
+def test_block_tails_on_and_off(torch_dev, oracle, tails, monkeypatch):
+    """What a block still has staged at its end leaves through a side buffer and a gather kernel (block tails, the default
+    where the buffer fits) or with one returning atomic per block (HAVAC_BLOCK_TAILS=0, and launches too big for a side
+    buffer): the same lists either way, on sparse hits (every tail fits), dense hits (tails that overflow their 128 slots
+    fall back to the atomic) and a short model x 100 Mbp."""
+    torch, dev = torch_dev
+    monkeypatch.setenv("HAVAC_BLOCK_TAILS", tails)
+    rng = np.random.default_rng(17)
+    for case in range(8):
+        nrows = int(rng.choice([1, 32, 64, 100, 1000, 3000]))
+        nseg = int(rng.integers(1, 12))
+        sym = synth.random_symbols(nseg * synth.SEGMENT, 500 + case)
+        if case % 2 == 0:
+            model = rng.integers(-100, 128, size=(nrows, 4)).astype(np.int8)        # dense: hundreds of records per block
+        else:
+            model, cons = synth.dfam_like_model(nrows, 600 + case)
+            synth.plant_homologs(sym, cons, sym.size, every=800, length=min(nrows, 200), sub=0.08)
+        got, = run_shards(torch, dev, synth.pack_2bit(sym), model, capacity=1 << 24)
+        want = oracle.ssv(sym, model, cap=1 << 24)
+        assert np.array_equal(got, want), (tails, case, nrows, nseg, got.size, want.size)
+    ncols = 100_012_032
+    model, cons = synth.dfam_like_model(48, 4300)
+    packed = synth.random_packed(ncols, 4301)
+    got, = run_shards(torch, dev, packed, model)
+    assert np.array_equal(got, whole_list(oracle, packed, model))
