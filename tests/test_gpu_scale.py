@@ -312,8 +312,8 @@ def test_passes_in_flight_give_the_same_lists(torch_dev, oracle):
 
 @pytest.mark.parametrize("nrows", [32, 64, 100])
 def test_short_models_whole_hit_list(torch_dev, oracle, nrows):
-    """Short single models x 100 Mbp: a wave walks several ADJACENT tiles (tiles_per_item > 1 in the launch, see
-    havac_dev.hip) and what it staged leaves at the end of all of them; the whole hit list against the checker."""
+    """Short single models x 100 Mbp (tiles of one to four chunks, 12,209 blocks that end within microseconds of each
+    other and leave their records through the block tails); the whole hit list against the checker."""
     torch, dev = torch_dev
     ncols = 100_012_032
     model, cons = synth.dfam_like_model(nrows, 4242 + nrows)
