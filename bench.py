@@ -12,11 +12,11 @@ is already resident in HBM: model padding copy + SSV kernel + hit compaction +
 ordering of the hit records into the reference's device order (+ for N > 1 the
 RCCL gather of the records to rank 0, where the rank lists concatenate to the
 ordered whole).  For passes of up to 1e12 cells three passes are in flight (--pipeline-depth), each with its own
-context, hit buffer and HIP stream: while the host waits for the hit count of pass k, orders
-its records and gathers them, the SSV kernel of pass k+1 runs; the SSV kernels themselves are
-chained back to back, never side by side, so their event-timed durations stay clean.  All K
-passes are complete when the timed region ends; `config.ms_per_step_strictly_serial` shows
-the same K passes with one in flight.
+context and hit buffer: while the host waits for the hit count of pass k, orders its records and gathers
+them (on the pass's own low-priority stream), the SSV kernel of pass k+1 runs; the SSV kernels of all
+passes are enqueued on one high-priority stream, back to back, never side by side, so their event-timed
+durations stay clean.  All K passes are complete when the timed region ends;
+`config.ms_per_step_strictly_serial` shows the same K passes with one in flight.
 
 Workloads (BASELINE.json configs):
   c2 (default)  one pHMM of L = 1024 rows x 100 Mbp (100,012,032 columns after padding to 12288) per GPU; N > 1 is
