@@ -65,7 +65,9 @@ FPGA_GCUPS = 1739.0                    # reference README.md:4 (Alveo U50), BASE
 # name -> (rows or None for the 1000-model collection, real symbols per unit, scaling); a unit is one GPU's share
 # for weak scaling and the whole database for strong scaling
 WORKLOADS = {
-    "c2": dict(rows=1024, real=100_000_000, scaling="weak", steps=20, warmup=3,
+    # (warm-up: the GPU needs ~10 launches of 2 ms to reach its clock under this load -- the kernel's duration falls from 2.11
+    # to 1.83 ms over the first ten launches of a run, profiles/r02b_kernel_stats_c2.csv -- so the default warm-up is 20 passes)
+    "c2": dict(rows=1024, real=100_000_000, scaling="weak", steps=50, warmup=20,
                label="C2: 1 pHMM L=1024 x 100 Mbp (100,012,032 columns padded to 12288) per GPU"),
     "c3": dict(rows=None, real=10_000_000, scaling="weak", steps=10, warmup=2,
                label="C3: 1000-model collection (L 50-2000, 503,329 rows concatenated) x 10 Mbp (10,002,432 columns) per GPU"),

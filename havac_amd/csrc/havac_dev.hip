@@ -256,13 +256,14 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     shard_tiles(t, nrows, col_begin, col_end, &tb, &te);
 
     HIP_TRY(c->err, hipEventRecord(c->ev[0], stream));
-    HIP_TRY(c->err, hipMemsetAsync(c->d_count, 0, sizeof(unsigned long long), stream));
-    hipLaunchKernelGGL(ssv_pad_model, dim3((model_words + 255) / 256), dim3(256), 0, stream,
-                       d_phmm, nrows, c->rows8, model_words);
-    // separator pairs score -128 twice in a row whatever the model says: with a mask every chunk tests every two steps
-    if (!c->pair_mask)
-        hipLaunchKernelGGL(ssv_chunk_flags, dim3((flag_words * 32 + 63) / 64), dim3(64), 0, stream,
-                           (const uint32_t*)c->rows8, t.nrows_padded, c->chunk_flags, flag_words);
+    // one launch: the padded copy of the model, the chunk flags, the cleared hit counter.  (Separator pairs score -128 twice
+    // in a row whatever the model says: with a mask there are no flags, every chunk tests every two steps.)
+    {
+        const uint32_t nflagwords = c->pair_mask ? 0u : flag_words;
+        const uint32_t threads = std::max(model_words, nflagwords * 32u);
+        hipLaunchKernelGGL(ssv_prepare_model, dim3((threads + 255) / 256), dim3(256), 0, stream, d_phmm, nrows, c->rows8, model_words,
+                           t.nrows_padded, c->chunk_flags, nflagwords, c->d_count);
+    }
     // sort key = segment | row | column in segment, each field only as wide as this problem needs
     unsigned row_bits = 1, seg_bits = 1;
     while ((1u << row_bits) < t.nrows_padded + 2u) row_bits++;

@@ -21,7 +21,7 @@
 //    low byte (0x7fff), and it stays recognisable until it saturates at the
 //    bottom, i.e. until the scores added after the crossing sum to -256 or less.
 //    That is why hits are looked for only once per FOUR steps wherever three
-//    consecutive model rows cannot sum below -255 (ssv_chunk_flags marks those
+//    consecutive model rows cannot sum below -255 (ssv_prepare_model marks those
 //    32-row chunks; elsewhere, and with separator masks, every two steps).
 //  * SKEWED PAIRS.  The two cells of a register sit on adjacent diagonals, and
 //    the high cell runs ONE ROW BEHIND the low cell: at step t the low cell is
@@ -87,7 +87,7 @@ constexpr uint32_t kCrossedBits = 0x00010001u;    // bit 0 of either cell: set o
 constexpr uint32_t kOutsideReset = 0x80008000u;   // match word "score -128" for both cells (separator pairs: two of them reset a diagonal)
 constexpr uint32_t kOutsideNeutral = 0u;          // match word "score 0": columns outside the matrix when there are no separators
 constexpr uint32_t kPadRow = 0u;                  // a row outside the model scores 0 for every symbol: it changes nothing and can never hit
-constexpr int kWindowSteps = 4;                   // steps between two hit tests where the model allows it (ssv_chunk_flags)
+constexpr int kWindowSteps = 4;                   // steps between two hit tests where the model allows it (ssv_prepare_model)
 
 // per-wave LDS: 16 step-pair tables of 17 entries x 8 B, the record stage
 constexpr int kPairStride = 17 * 8;               // 16 symbol-pair codes + the "outside the matrix" entry
@@ -126,31 +126,37 @@ __device__ __forceinline__ uint64_t record_to_key(uint64_t rec, uint32_t row_bit
 // padding row leaves every score as it is and can never hit; it must not LOWER a
 // score either, or a crossing on the model's last rows could lose its mark before
 // the next hit test, see step_window).  nrows_padded + kModelSlack words.
-__global__ void ssv_pad_model(const int8_t* __restrict__ phmm, uint32_t nrows,
-                              uint32_t* __restrict__ rows, uint32_t nwords) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nwords) return;
-    rows[i] = (i >= 1 && i <= nrows) ? reinterpret_cast<const uint32_t*>(phmm)[i - 1] : kPadRow;
+__device__ __forceinline__ uint32_t padded_model_row(const uint32_t* __restrict__ phmm_rows, uint32_t nrows, uint32_t i) {
+    return (i >= 1 && i <= nrows) ? phmm_rows[i - 1] : kPadRow;
 }
 
 // Which 32-step chunks may test for hits every FOUR steps instead of every two.  A crossed cell is recognised by its
 // low byte (0x7fff), and it loses that mark only by saturating at the bottom, i.e. when the scores added after the
 // crossing sum to -256 or less.  Inside a window of four steps at most three steps follow a crossing, so a chunk is
 // safe when no three consecutive rows it touches (rows 32c-1 .. 32c+31: the high cells run one row behind) can sum
-// below -255 whatever the symbols are.  One bit per chunk; `rows` is the padded model of ssv_pad_model.
-__global__ void ssv_chunk_flags(const uint32_t* __restrict__ rows, uint32_t nrows_padded, uint32_t* __restrict__ flags,
-                                uint32_t nwords) {
+// below -255 whatever the symbols are.  One bit per chunk; the same kernel writes the padded model.
+// ONE launch prepares a pass: thread i writes word i of the padded model, thread c the flag of chunk c (from the model
+// itself, not from the padded copy: the two halves do not depend on each other), thread 0 clears the hit counter.  As
+// three dispatches (memset, pad, flags) in front of every SSV kernel the preparation cost ~30 us of dispatch gaps per
+// pass -- 1.5 % of a C2 step -- for 10 us of work.
+__global__ void ssv_prepare_model(const int8_t* __restrict__ phmm, uint32_t nrows, uint32_t* __restrict__ rows, uint32_t nwords,
+                                  uint32_t nrows_padded, uint32_t* __restrict__ flags, uint32_t nflagwords /* 0: no flags */,
+                                  unsigned long long* __restrict__ hit_count) {
+    const uint32_t* const phmm_rows = reinterpret_cast<const uint32_t*>(phmm);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *hit_count = 0ull;
+    if (i < nwords) rows[i] = padded_model_row(phmm_rows, nrows, i);
+    if (nflagwords == 0) return;
     // one thread per chunk, 64 chunks = two flag words per wave
-    const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t chunk = i;
     const uint32_t p0 = chunk * kChunkRows;
-    const uint32_t limit = nrows_padded + kModelSlack;
     bool safe = false;
-    if (chunk / 32 < nwords && p0 < nrows_padded + kChunkRows) {
-        // rows p0-1 .. p0+31 are rows[p0 .. p0+32]: the lowest score of each (at most 0; 0 beyond the array) ...
+    if (chunk / 32 < nflagwords && p0 < nrows_padded + kChunkRows) {
+        // rows p0-1 .. p0+31 are padded rows p0 .. p0+32: the lowest score of each (at most 0; 0 beyond the model) ...
         int lowest[kChunkRows + 1];
 #pragma unroll
         for (int k = 0; k <= kChunkRows; k++) {
-            const uint32_t r = p0 + k < limit ? rows[p0 + k] : 0u;
+            const uint32_t r = padded_model_row(phmm_rows, nrows, p0 + k);
             int m = 0;
 #pragma unroll
             for (int a = 0; a < 4; a++) m = min(m, (int)(int8_t)(r >> (8 * a)));
@@ -163,7 +169,7 @@ __global__ void ssv_chunk_flags(const uint32_t* __restrict__ rows, uint32_t nrow
     }
     const unsigned long long bits = __ballot(safe);
     const uint32_t lane = threadIdx.x & 63, word = chunk / 32;
-    if (word < nwords && (lane & 31) == 0) flags[word] = (uint32_t)(bits >> (lane & 32));
+    if (word < nflagwords && (lane & 31) == 0) flags[word] = (uint32_t)(bits >> (lane & 32));
 }
 
 // ---------------------------------------------------------------------------
@@ -741,7 +747,7 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
 
 // Steps 4Q .. 4Q+3 of the chunk.  `cur` is left untouched (the first add is not in place) and holds the scores the window
 // started from; `nxt` receives the scores after the four steps; the next window swaps the two sets.  One hit test at
-// the end where ssv_chunk_flags says that is exact (`safe`, wave-uniform), else one more in the middle.
+// the end where the chunk flags (ssv_prepare_model) say that is exact (`safe`, wave-uniform), else one more in the middle.
 template <bool Trace, int Q, int... I>
 __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
                                             uint32_t safe, const HitSink& sink, uint32_t& staged, uint32_t step0,
@@ -1041,7 +1047,7 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         fetch_symbols(p_begin + 32, z, mine.lane8);
 
         bool go_on = true;                 // wave-uniform
-        // one bit per chunk: may the chunk look for hits every four steps only (ssv_chunk_flags)?  never with separators.
+        // one bit per chunk: may the chunk look for hits every four steps only (ssv_prepare_model)?  never with separators.
         // The word of the current 1024 rows and, loaded a whole block ahead, the next one: the test never waits for memory
         uint32_t safe_now = safe_chunks ? safe_chunks[p_begin >> 10] : 0u;
         uint32_t safe_next = safe_chunks ? safe_chunks[(p_begin >> 10) + 1] : 0u;
