@@ -1,54 +1,114 @@
-"""VALU / LDS / SALU instruction counts of the SSV kernel's chunk loop on its usual path (no separators, no matrix edge,
-four-step windows), per region: the chunk's prologue, its eight windows, its epilogue.  python tools/asm_chunk.py [file.s] [-v]"""
+"""Instruction counts of the SSV kernel's chunk loop on its USUAL path (no separators, no matrix edge, four-step windows,
+no hit), from the ISA that `bash tools/kstat.sh` leaves in build/asm2.   python tools/asm_chunk.py [file.s] [-v]
+
+The usual path is taken to be the path from the chunk loop's header to its back edge with the FEWEST vector
+instructions: at a conditional branch to a label a few lines further down (the skip over, or the entry into, a rare
+block: a window entry outside the matrix, the middle hit test of an "unsafe" chunk, the symbol fetch at the matrix's
+edge) both ways are tried; a conditional branch to a far label leaves for a slow path and is not followed."""
 import collections
+import os
+import re
 import sys
 
-path = next((a for a in sys.argv[1:] if a.endswith(".s")), "havac_dev-hip-amdgcn-amd-amdhsa-gfx950.s")
+sys.setrecursionlimit(100000)
+default = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "asm2",
+                       "havac_dev-hip-amdgcn-amd-amdhsa-gfx950.s")
+path = next((a for a in sys.argv[1:] if a.endswith(".s")), default)
 verbose = "-v" in sys.argv
 lines = open(path).read().split("\n")
 start = [i for i, l in enumerate(lines) if l.startswith("_ZN5havac15ssv_diag_kernel")][0]
-body = lines[start:]
-w0 = [i for i, l in enumerate(body) if "expand_for_windowILi0E" in l and l.startswith(".LBB")][0]
-sw = [i for i, l in enumerate(body) if "step_windowsIJ" in l and l.startswith(".LBB")][0]
-hdr = [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l and i < w0][-1]
-end = [i for i, l in enumerate(body) if i > sw and "s_branch" in l or (i > sw and "s_cbranch" in l and "LBB" in l)][0:40]
+stop = [i for i, l in enumerate(lines) if i > start and ".Lfunc_end" in l][0]
+body = lines[start:stop]
+label_at = {l.split(":")[0]: i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
+first_window = [i for i, l in enumerate(body) if "expand_for_windowILi0E" in l and l.startswith(".LBB")][0]
+after_windows = [i for i, l in enumerate(body) if "step_windowsI" in l and l.startswith(".LBB")][0]
+header = [i for i, l in enumerate(body) if "Loop Header" in l and i < first_window][-1]
+NEAR = 60          # lines: a rare block is shorter than this
 
 
-def count(lo, hi):
-    c = collections.Counter()
-    skip = False
-    last = ""
-    for l in body[lo:hi]:
-        t = l.split(";")[0].strip()
-        if not t:
+def branch_target(i):
+    t = body[i].split(";")[0].strip()
+    if t.startswith("s_branch") or t.startswith("s_cbranch"):
+        return label_at.get(t.split()[-1])
+    return None
+
+
+# the chunk loop's back edge: the last branch behind the windows that goes to the header (or to a block that falls into it)
+back_edges = [i for i in range(after_windows, len(body)) if (branch_target(i) or 0) and header - 15 <= branch_target(i) <= header]
+loop_end = back_edges[0]
+for i in back_edges:
+    if i - loop_end < 400:
+        loop_end = i
+
+
+def instruction(i):
+    t = body[i].split(";")[0].strip()
+    if not t or t.endswith(":") or t.startswith("."):
+        return None
+    return t
+
+
+memo = {}
+
+
+def best(i):
+    """-> (vector instructions, list of instruction indices) of the cheapest way from line i to the back edge"""
+    path_here = []
+    while True:
+        if i in memo:
+            n, rest = memo[i]
+            return n + sum(1 for k in path_here if instruction(k).startswith("v_")), path_here + rest
+        if i > loop_end:                                             # left the loop: not a way round it
+            return 10 ** 9, path_here
+        t = instruction(i)
+        if t is None:
+            i += 1
             continue
-        if t.endswith(":"):
-            skip = False
-            continue
-        if t.startswith("."):
-            continue
+        path_here.append(i)
         op = t.split()[0]
-        if skip:
-            continue
-        c[op] += 1
-        if verbose:
-            print("   ", t[:100])
-        # the block behind a forward branch over it is a rare path: special entries, the middle test of unsafe chunks
-        if op.startswith("s_cbranch") and not t.split()[-1].startswith(".LBB7_1") is None:
-            skip = True
-        last = op
-    return c
+        if op == "s_branch" or op.startswith("s_cbranch"):
+            target = label_at.get(t.split()[-1])
+            if target is not None and header - 15 <= target <= header:
+                break                                                # the back edge
+            if target is not None and target < header - 15 and op == "s_branch":
+                return 10 ** 9, path_here                            # out of the loop
+            if target is not None and op == "s_branch":
+                i = target
+                continue
+            if target is not None and 0 < target - i < NEAR:          # both ways
+                a = best(i + 1)
+                b = best(target)
+                memo_key = path_here[0]
+                n, rest = a if a[0] <= b[0] else b
+                mine = sum(1 for k in path_here if instruction(k).startswith("v_"))
+                memo[memo_key] = (n + mine, path_here + rest)
+                return memo[memo_key]
+        i += 1
+    mine = sum(1 for k in path_here if instruction(k).startswith("v_"))
+    return mine, path_here
 
 
-# the loop ends at the back edge: first s_branch/s_cbranch to the header label after the windows
-hname = body[hdr].split(":")[0]
-back = [i for i, l in enumerate(body) if i > sw and hname in l and ("s_branch" in l or "s_cbranch" in l)]
-stop = back[0] + 1 if back else sw + 120
-for name, (lo, hi) in dict(prologue=(hdr, w0), windows=(w0, sw), epilogue=(sw, stop)).items():
+_, usual = best(header + 1)
+per_region = collections.defaultdict(collections.Counter)
+for k in usual:
+    region = "prologue" if k < first_window else ("windows" if k < after_windows else "epilogue")
+    t = instruction(k)
+    per_region[region][t.split()[0]] += 1
     if verbose:
-        print("==", name)
-    c = count(lo, hi)
-    v = sum(n for k, n in c.items() if k.startswith("v_"))
-    print(name, "VALU", v, "LDS", sum(n for k, n in c.items() if k.startswith("ds_")), "SALU", sum(n for k, n in c.items() if k.startswith("s_")),
-          "VMEM", sum(n for k, n in c.items() if k.startswith(("global_", "buffer_"))))
-    print("   ", {k: n for k, n in c.most_common(40) if k.startswith("v_")})
+        print(f"{region:9s} {t[:100]}")
+
+
+def summary(c):
+    def total(prefixes):
+        return sum(n for k, n in c.items() if k.startswith(prefixes))
+    return (f"VALU {total(('v_',))}  LDS {total(('ds_',))}  VMEM {total(('global_', 'buffer_', 'scratch_'))}  "
+            f"SALU/waits/branches {total(('s_',))}")
+
+
+everything = collections.Counter()
+for name in ("prologue", "windows", "epilogue"):
+    c = per_region[name]
+    everything.update(c)
+    print(f"{name:9s} {summary(c)}")
+    print("          ", {k: n for k, n in c.most_common(40) if k.startswith("v_")})
+print(f"{'chunk':9s} {summary(everything)}")
