@@ -903,6 +903,9 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
     __shared__ WaveLds wave_lds[kWavesPerBlock];
 
     const uint32_t lane = threadIdx.x & 63;
+    // a separator mask is in use exactly when there are no chunk flags; as a 32-bit SGPR flag tested afresh (fresh_uniform), not a
+    // lane mask that is copied through -- and once spilled from -- a VGPR
+    const uint32_t has_mask = opaque_uniform(safe_chunks == nullptr ? 1u : 0u);
     // readfirstlane: everything derived from the tile index is wave-uniform (SALU branches, scalar address math)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds* const lds = &wave_lds[wave];
@@ -924,7 +927,7 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         // Without separators it scores 0: a cell outside the matrix keeps what it has (0 before a diagonal enters at
         // column 0; behind the last column nothing is reported any more) and a mark is never lost there.  With a
         // separator mask the same entry scores -128: two of them reset every diagonal through a separator pair.
-        const uint32_t outside = !safe_chunks ? kOutsideReset : kOutsideNeutral;
+        const uint32_t outside = has_mask ? kOutsideReset : kOutsideNeutral;
         *(lds_words_out_t)(uintptr_t)(table_base + my_pair * kPairStride + kOutsideCode) = u32x2{outside, outside};
     }
 
@@ -1011,13 +1014,13 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             if (!edge) {                                                  // the usual case: one coalesced load, uniform base + lane offset
                 // (lane8 comes fresh from LDS in this block: its zero-extension folds into the load's "SGPR base + 32-bit VGPR offset" form)
                 w = *reinterpret_cast<const uint2*>(base + lane8);
-                if (!safe_chunks) z.separators = rare_args()->pair_mask[(first >> 5) + (lane8 >> 3)];
+                if (fresh_uniform(has_mask)) z.separators = rare_args()->pair_mask[(first >> 5) + (lane8 >> 3)];
             } else if ((int32_t)(lane8 * 4) >= z.valid_lo && (int32_t)(lane8 * 4) + 32 <= z.valid_hi) {
                 w = *reinterpret_cast<const uint2*>(base + lane8);
-                if (!safe_chunks) z.separators = rare_args()->pair_mask[(first >> 5) + (lane8 >> 3)];
+                if (fresh_uniform(has_mask)) z.separators = rare_args()->pair_mask[(first >> 5) + (lane8 >> 3)];
             }
             uint32_t special = edge;                                      // from scalars and a ballot only: stays on the scalar unit
-            if (!safe_chunks) special |= __any(z.separators != 0) ? 1u : 0u;
+            if (fresh_uniform(has_mask)) special |= __any(z.separators != 0) ? 1u : 0u;
             z.special = opaque_uniform(special);
             prepare_symbols(z, w.x, w.y);
         };
@@ -1102,7 +1105,7 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
     const uint32_t split_rows = rare_args()->rows_per_block;
     if (split_rows) {
         __shared__ uint32_t block_ticket;
-        if (threadIdx.x == 0) block_ticket = __hip_atomic_fetch_add(rare_args()->tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 0 && fresh_lane() == 0) block_ticket = __hip_atomic_fetch_add(rare_args()->tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         first_item = __builtin_amdgcn_readfirstlane(block_ticket) * kWavesPerBlock;
     }
@@ -1137,7 +1140,7 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
     const rare_args_t rare = rare_args();
     uint64_t* const tails = rare->tails;
     if (tails && total <= (uint32_t)kTailSlots) {
-        if (threadIdx.x == 0) rare->tail_counts[blockIdx.x] = total;
+        if (wave == 0 && lane_again == 0) rare->tail_counts[blockIdx.x] = total;
         if (staged) {
             const uint32_t row_bits = rare->row_bits;
             uint64_t* const mine = tails + (size_t)blockIdx.x * kTailSlots + before_me;
@@ -1145,7 +1148,7 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         }
         return;
     }
-    if (threadIdx.x == 0) {
+    if (wave == 0 && lane_again == 0) {      // (not threadIdx.x: it would sit in a VGPR -- in scratch -- from the kernel's first instruction on)
         if (tails) rare->tail_counts[blockIdx.x] = 0;
         block_base = total ? atomicAdd(rare->hit_count, (unsigned long long)total) : 0ull;
     }

@@ -350,11 +350,11 @@ def test_tiles_per_item_forced_on_small_problems(torch_dev, oracle, per_item, mo
     assert np.array_equal(np.concatenate(parts), oracle.ssv(sym, model))
 
 
-@pytest.mark.parametrize("tails", ["0", "1"])
+@pytest.mark.parametrize("tails", ["0", "1", "2"])
 def test_block_tails_on_and_off(torch_dev, oracle, tails, monkeypatch):
-    """What a block still has staged at its end leaves through a side buffer and a gather kernel (block tails, the default
-    where the buffer fits) or with one returning atomic per block (HAVAC_BLOCK_TAILS=0, and launches too big for a side
-    buffer): the same lists either way, on sparse hits (every tail fits), dense hits (tails that overflow their 128 slots
+    """What a block still has staged at its end leaves through a side buffer and a gather kernel (block tails: the default for
+    items of up to 512 rows, HAVAC_BLOCK_TAILS=2 forces them for taller ones) or with one returning atomic per block
+    (HAVAC_BLOCK_TAILS=0, tall items, launches too big for a side buffer): the same lists either way, on sparse hits (every tail fits), dense hits (tails that overflow their 128 slots
     fall back to the atomic) and a short model x 100 Mbp."""
     torch, dev = torch_dev
     monkeypatch.setenv("HAVAC_BLOCK_TAILS", tails)
