@@ -54,11 +54,21 @@
 //    crossings are reported and put back to score 0 on the way (0x7fff + 1 =
 //    0x8000; test/softSsv/SoftSsv.cpp:43-44), and the exact result is written
 //    over the lane's register.  Records go to an LDS stage and leave with one
-//    returning atomic per burst of 128 and one per block at the end of the
-//    tile; they are put in the FPGA's order afterwards.
+//    returning atomic per burst of 128; what a block still has staged when it
+//    ends leaves with one atomic per block, or -- short models, whose blocks end
+//    faster than one counter word can answer -- through the block's own slots of
+//    a side buffer and a small gather kernel (block tails).  The records are put
+//    in the FPGA's order afterwards.
+//  * SIX WAVES PER SIMD: 80 VGPRs (two score sets of 16, 16 match words in
+//    flight, ~19 window addresses, a few temporaries) and nothing else kept in
+//    a register through the hot loop: no lane number (per-lane constants come
+//    from LDS with ds_read_addtid_b32), no launch parameter that is needed
+//    rarely (SsvRare: read from the kernarg segment where it is used), no
+//    scratch.
 //
-// Roofline: integer VALU issue; HBM
-// traffic is N/4 + 4*rows + 8*hits bytes per launch, thousands of cells per byte.
+// Roofline: integer VALU issue and, at the same ceiling, LDS bandwidth (SURVEY.md
+// section 8d); HBM traffic is N/4 + 4*rows + 8*hits bytes
+// per launch, thousands of cells per byte.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
