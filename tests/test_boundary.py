@@ -97,3 +97,39 @@ def test_shard_arithmetic_is_host_only():
         assert sum(shard_cells(n, rows, r, world) for r in range(world)) == n * rows
         widths = [e - b for b, e in spans]
         assert max(widths) - min(widths) <= 12288
+
+
+def test_ssv_kernel_resources():
+    """What the hot kernel's speed rests on, read from the metadata of the code object inside libhavac_dev.so: 80 VGPRs
+    (= six waves per SIMD), no scratch, no register spills, 14 KB of LDS per workgroup.  A change
+    that costs a wave per SIMD costs 3 % and is easy to miss on a GPU box; here it fails on the CPU."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not all(os.path.isfile(os.path.join(llvm, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
+        pytest.skip("ROCm's LLVM tools are not installed here")
+    lib = os.path.join(ROOT, "havac_amd", "libhavac_dev.so")
+    tmp = tempfile.mkdtemp(prefix="havac_co_")
+    try:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "gfx950.hsaco")
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    kernels = {}
+    for block in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        kernels[name] = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|sgpr_spill_count|vgpr_spill_count|private_segment_fixed_size|"
+                                                         r"group_segment_fixed_size|max_flat_workgroup_size):\s+(\d+)", block)}
+    hot = [v for k, v in kernels.items() if "ssv_diag_kernel" in k and "traced" not in k]
+    assert len(hot) == 1, sorted(kernels)
+    hot = hot[0]
+    assert hot["vgpr_count"] <= 80, hot                      # 512 / 6 in granules of 8: six waves per SIMD
+    assert hot["private_segment_fixed_size"] == 0, hot       # no scratch
+    assert hot["sgpr_spill_count"] == 0 and hot["vgpr_spill_count"] == 0, hot
+    assert hot["group_segment_fixed_size"] <= 160 * 1024 // 6, hot      # six workgroups per CU fit the LDS
+    assert any("ssv_diag_kernel_traced" in k for k in kernels) and any("ssv_gather_tails" in k for k in kernels)
