@@ -118,6 +118,7 @@ def test_ssv_kernel_resources():
         subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
                         "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
         notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+        symbols = subprocess.run([os.path.join(llvm, "llvm-readelf"), "-s", co], check=True, capture_output=True, text=True).stdout
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     kernels = {}
@@ -133,3 +134,9 @@ def test_ssv_kernel_resources():
     assert hot["sgpr_spill_count"] == 0 and hot["vgpr_spill_count"] == 0, hot
     assert hot["group_segment_fixed_size"] <= 160 * 1024 // 6, hot      # six workgroups per CU fit the LDS
     assert any("ssv_diag_kernel_traced" in k for k in kernels) and any("ssv_gather_tails" in k for k in kernels)
+    # The kernel body reads rarely used arguments from the kernarg segment (rare_args); inside a function that is really CALLED
+    # the pointer to that segment is null.  Only these two device functions may exist as functions of their own -- both are
+    # handed what they need -- and in particular no outlined piece of the kernel body (its item lambda).
+    functions = {line.split()[-1] for line in symbols.splitlines() if " FUNC " in line and "havac" in line}
+    callees = {f for f in functions if not re.match(r"^_ZN5havac\d+ssv_[a-z_]+E", f)}      # the kernels are havac::ssv_*
+    assert all(("flush_full" in f) or ("trace_cells_of_step" in f) for f in callees), sorted(callees)
