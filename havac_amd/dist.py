@@ -129,7 +129,9 @@ class ShardedSsv:
         stream = self.kernel_stream if self.kernel_stream is not None else torch.cuda.current_stream(self.device)
         if self.kernel_stream is not None:
             stream.wait_stream(torch.cuda.current_stream(self.device))      # the caller's inputs
-            stream.wait_stream(slot.stream)                                  # the slot's last gather has read its hit buffer
+            if self.world > 1 or self.gather_when_alone:
+                stream.wait_stream(slot.stream)                              # the slot's last gather has read its hit buffer
+                #                                                              (alone, collect() has waited for the ordering on the host)
         slot.ctx.enqueue(d_seq.data_ptr(), nsymbols, d_phmm.data_ptr(), nrows, slot.hits.data_ptr(),
                          slot.hits.numel(), self.rank, self.world, 0, stream.cuda_stream)
         self.in_flight.append(self.next_slot)
