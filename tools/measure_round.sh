@@ -1,6 +1,7 @@
 #!/bin/bash
 # One measurement round on the GPU box: bench lines of c2 / c3 / c5, rocprofv3 kernel stats of each, PMC passes of each,
-# the model-height sweep.  bash tools/measure_round.sh <tag>   -> gpurun_out/<tag>_*
+# the model-height sweep.  bash tools/measure_round.sh <tag> [all]   -> gpurun_out/<tag>_*   (`all`: + C4 on one GPU, the
+# end-to-end series, the PCIe-inclusive rate; ~2 minutes of GPU time without, ~4 with)
 set -e
 tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -13,3 +14,10 @@ for w in c2 c3 c5; do
 done
 python3 tools/rows_probe.py > gpurun_out/${tag}_rows_sweep.txt 2>/dev/null
 cat gpurun_out/${tag}_rows_sweep.txt
+if [ "$2" = "all" ]; then      # + C4 on one GPU (a 9 s launch per pass), the end-to-end series, the PCIe-inclusive rate
+    python3 bench.py --workload c4 --no-pmc > gpurun_out/${tag}_bench_c4_one_gpu.json 2> gpurun_out/${tag}_bench_c4.err || echo "bench c4 failed"
+    tail -c 300 gpurun_out/${tag}_bench_c4_one_gpu.json; echo
+    python3 tools/e2e_series.py > gpurun_out/${tag}_e2e_series.txt 2>&1 || echo "e2e series failed"
+    tail -14 gpurun_out/${tag}_e2e_series.txt
+    python3 tools/pcie_inclusive.py 2>/dev/null | tee gpurun_out/${tag}_pcie_inclusive_c2.txt
+fi
