@@ -1,4 +1,4 @@
-import sys, os, time
+import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 from havac_amd import synth
