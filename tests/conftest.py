@@ -19,9 +19,10 @@ def pytest_configure(config):
 
 
 def golden_names():
-    """the SSV fixtures (packed sequence, model, hits); g7_* holds the projection's known answers (test_projection_golden.py)"""
+    """the SSV fixtures (packed sequence, model, hits); g7_* holds the projection's known answers (test_projection_golden.py),
+    g8_* the reference's per-(model, record) SSV on small files (test_boundary_golden.py)"""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith("g7_")]
+    return [n for n in names if not n.startswith(("g7_", "g8_"))]
 
 
 def load_golden(name):
@@ -34,3 +35,17 @@ def oracle():
     from oracle import pyoracle
     pyoracle.build()
     return pyoracle
+
+
+def g8_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "g8_boundary_*.npz")))
+
+
+def load_g8(name, tmp_path):
+    """-> (fasta path, hmm path, p-value, HitsFromSsv rows as sorted tuples (record, model, position, row), npz)"""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    fa, hmm = tmp_path / (name + ".fa"), tmp_path / (name + ".hmm")
+    fa.write_text(str(z["fasta"]))
+    hmm.write_text(str(z["hmm"]))
+    assert bool(z["single_equals_table"])
+    return str(fa), str(hmm), float(z["p"]), sorted(tuple(int(v) for v in row) for row in z["hits"]), z

@@ -77,12 +77,51 @@ def test_product_never_touches_the_oracle():
         for f in files:
             if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".sh")):
                 text = open(os.path.join(base, f), errors="ignore").read()
-                if re.search(r"(?m)^\s*(from|import)\s+oracle\b|pyoracle|liboracle|ssv_oracle|softssv_ref", text):
+                if re.search(r"(?m)^\s*(from|import)\s+oracle\b|pyoracle|liboracle|ssv_oracle|softssv_ref|refhost|ssv_ref2", text):
                     bad.append(os.path.join(base, f))
     assert not bad
     for lib in (_lib.LIB_PATH, havac.HOST_LIB_PATH):
         needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
-        assert "oracle" not in needed and "softssv" not in needed
+        assert "oracle" not in needed and "softssv" not in needed and "refhost" not in needed
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert "refhost" not in bench and "_ref2" not in bench
+
+
+REFERENCE_HOST = "/root/reference/host/Havac.cpp"
+
+
+@pytest.mark.skipif(not os.path.isfile(REFERENCE_HOST), reason="the reference tree is only in the build container")
+def test_reference_host_code_compiles_against_the_committed_binding():
+    """INTEGRATION.md section B as a build, not as prose: host/Havac.cpp, host/phmm/PhmmPreprocessor.cpp,
+    host/sequence/SequencePreprocessor.cpp and PhmmReprojection/PhmmReprojection.cpp of the reference compile UNCHANGED,
+    from where they lie, against integration/HavacHwClient.hpp + include/havac_dev.h (tests/refhost/Makefile), and the
+    result links to libhavac_dev.so alone.  Round 2's shim lived in a markdown block, lacked <iostream>, and did not
+    compile; this test is what keeps that from happening again."""
+    from refhost import binding
+    assert binding.build_if_possible()
+    have = subprocess.run(["nm", "-DC", "--defined-only", binding.REFHOST_LIB], capture_output=True, text=True, check=True).stdout
+    for symbol in ("Havac::loadPhmm", "Havac::loadSequence", "Havac::runHardwareClientAsync", "Havac::getHitsFromFinishedRun",
+                   "Havac::generatePhmmLenPrefixSums", "SequencePreprocessor::getCompressedSymbol",
+                   "PhmmPreprocessor::getProcessedPhmmData", "p7HmmProjectForThreshold256", "HavacHwClient::getHitList"):
+        assert symbol in have, symbol
+    needed = subprocess.run(["readelf", "-d", binding.REFHOST_LIB], capture_output=True, text=True).stdout
+    assert "libhavac_dev.so" in needed and "libhavac.so" not in needed and "xrt" not in needed
+    # the markdown points at the committed header; it carries declarations only, no second implementation to go stale
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "integration/HavacHwClient.hpp" in doc and "havac_dev_destroy(dev)" not in doc
+    assert os.path.isfile(binding.SSV_REF2_LIB)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_reference_havac_refuses_to_start_without_a_device():
+    """The reference's constructor (host/Havac.cpp:20-31) over the binding: no device -> std::runtime_error out of
+    make_shared<HavacHwClient>, nothing is computed anywhere else."""
+    from refhost import binding
+    if not os.path.isfile(binding.REFHOST_LIB):
+        pytest.skip("tests/_refhost was not built")
+    with pytest.raises(binding.RefHostError) as e:
+        binding.ReferenceHavac(0, 0.02)
+    assert e.value.code == -3
 
 
 def test_shard_arithmetic_is_host_only():
