@@ -24,6 +24,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "ssv_kernels.hip.h"
+#include "hit_order.hip.h"
 
 using namespace havac;
 
@@ -98,13 +99,25 @@ struct havac_ssv_ctx {
     const uint16_t* pair_mask = nullptr;                // optional separator bitmap (boundary mode), caller-owned
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     uint64_t* sort_alt = nullptr; size_t sort_alt_count = 0;
+    // bucket ordering (hit_order.hip.h): per bucket a count / cursor and an offset, the list of large buckets, shared state
+    uint32_t* bucket_counts = nullptr; uint64_t* bucket_offsets = nullptr; uint32_t* bucket_large = nullptr; size_t bucket_alloc = 0;
+    OrderState* order_state = nullptr;         // device
+    OrderState* h_order_state = nullptr;       // pinned copy the host reads after the ordering
+    bool bucket_ordered = false;               // the pending pass went through the bucket ordering (else: the radix sort)
+    uint64_t order_count = 0;                  // records of the pending pass's ordering
+    uint64_t first_segment = 0, nsegments = 0; // the shard's segments (bucket numbering)
+    int tune_ordering = -1;                    // -1 / 1: bucket ordering, 0: always the radix sort (experiments, tests)
+    uint32_t last_order_buckets = 0, last_order_largest = 0; int last_order_path = 0;   // what the last pass's ordering did (tests, tools)
     unsigned long long* d_count = nullptr;
     unsigned long long* h_count = nullptr;     // pinned
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pass start, kernel start, kernel end, records ordered, count on the host
     CellRecord* trace_cells = nullptr; uint32_t trace_row0 = 0, trace_rows = 0, trace_cols = 0; uint64_t trace_col0 = 0;   // per-cell trace window (debugging)
     hipStream_t order_stream = nullptr;        // optional: where finish() orders the records (default: the enqueue's stream)
+    // experiment knobs (havac_ssv_set_tuning): -1 = the library decides
+    int tune_rows_per_block = -1, tune_tiles_per_item = -1, tune_block_tails = -1;
     // the pass enqueue() started and finish() completes
-    bool pending = false;
+    bool pending = false, ordering = false;    // enqueue() done; finish_begin() done
+    uint64_t found = 0;
     hipStream_t stream = nullptr;
     uint64_t* d_hits = nullptr;
     uint64_t hit_capacity = 0;
@@ -135,6 +148,9 @@ extern "C" int havac_ssv_ctx_create(havac_ssv_ctx** out) {
     }
     if (hipHostMalloc(&c->h_count, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return fail(HAVAC_E_NOMEM);
     c->h_count[0] = c->h_count[1] = 0;
+    if (hipMalloc(&c->order_state, sizeof(OrderState)) != hipSuccess) return fail(HAVAC_E_NOMEM);
+    if (hipHostMalloc(&c->h_order_state, sizeof(OrderState), hipHostMallocDefault) != hipSuccess) return fail(HAVAC_E_NOMEM);
+    std::memset(c->h_order_state, 0, sizeof(OrderState));
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) return fail(HAVAC_E_RUNTIME);
     *out = c;
@@ -152,6 +168,11 @@ extern "C" void havac_ssv_ctx_destroy(havac_ssv_ctx* c) {
     if (c->tail_counts) (void)hipFree(c->tail_counts);
     if (c->sort_tmp) (void)hipFree(c->sort_tmp);
     if (c->sort_alt) (void)hipFree(c->sort_alt);
+    if (c->bucket_counts) (void)hipFree(c->bucket_counts);
+    if (c->bucket_offsets) (void)hipFree(c->bucket_offsets);
+    if (c->bucket_large) (void)hipFree(c->bucket_large);
+    if (c->order_state) (void)hipFree(c->order_state);
+    if (c->h_order_state) (void)hipHostFree(c->h_order_state);
     if (c->d_count) (void)hipFree(c->d_count);
     if (c->h_count) (void)hipHostFree(c->h_count);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -190,6 +211,23 @@ extern "C" int havac_ssv_set_order_stream(havac_ssv_ctx* c, void* hip_stream) {
     if (!c) return HAVAC_E_ARGUMENT;
     if (c->pending) { c->err = "a pass is in flight: set the ordering stream between passes"; return HAVAC_E_LOGIC; }
     c->order_stream = (hipStream_t)hip_stream;
+    return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_set_tuning(havac_ssv_ctx* c, int rows_per_block, int tiles_per_item, int block_tails, int ordering) {
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (c->pending) { c->err = "a pass is in flight: change the tuning between passes"; return HAVAC_E_LOGIC; }
+    if (block_tails > 2 || (rows_per_block > 0 && rows_per_block < 1024)) { c->err = "bad tuning value"; return HAVAC_E_ARGUMENT; }
+    c->tune_rows_per_block = rows_per_block; c->tune_tiles_per_item = tiles_per_item; c->tune_block_tails = block_tails;
+    c->tune_ordering = ordering;
+    return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_last_ordering(havac_ssv_ctx* c, int* path, uint32_t* nbuckets, uint32_t* largest_bucket) {
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (path) *path = c->last_order_path;
+    if (nbuckets) *nbuckets = c->last_order_buckets;
+    if (largest_bucket) *largest_bucket = c->last_order_largest;
     return HAVAC_OK;
 }
 
@@ -280,19 +318,16 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     const uint64_t slots = (uint64_t)c->resident_blocks * kWavesPerBlock;
     uint32_t rows_per_block = 0;
     if (te > tb && t.nrows_padded >= kRowsPerBlock + 1024 && L.ntiles < kSplitBelowRounds * slots) rows_per_block = kRowsPerBlock;
-    if (const char* forced = std::getenv("HAVAC_ROWS_PER_BLOCK")) {          // experiments: 0 = never split
-        rows_per_block = (uint32_t)std::atoi(forced) / kChunkRows * kChunkRows;
+    if (c->tune_rows_per_block >= 0) {                                        // experiments (havac_ssv_set_tuning): 0 = never split
+        rows_per_block = (uint32_t)c->tune_rows_per_block / 1024u * 1024u;    // whole chunk-flag words
         if (rows_per_block >= t.nrows_padded) rows_per_block = 0;
     }
     const bool split = rows_per_block != 0;
-    // A wave can walk several adjacent tiles (ssv_kernels.hip.h, "items"; HAVAC_TILES_PER_ITEM).  Built for short models, whose
+    // A wave can walk several adjacent tiles (ssv_kernels.hip.h, "items"; havac_ssv_set_tuning).  Built for short models, whose
     // blocks queued up at the hit counter; the block tails removed that queue altogether, and with them groups of two
     // tiles are 1-3 % SLOWER than single tiles (fewer, longer items balance worse): off unless forced.
     uint32_t tiles_per_item = 1;
-    if (const char* forced = std::getenv("HAVAC_TILES_PER_ITEM")) {           // experiments
-        tiles_per_item = (uint32_t)std::max(1, std::atoi(forced));
-        if (split) tiles_per_item = 1;
-    }
+    if (c->tune_tiles_per_item >= 1 && !split) tiles_per_item = (uint32_t)c->tune_tiles_per_item;      // experiments
     L.tiles_per_item = tiles_per_item;
     uint32_t nblocks = 0;
     if (te > tb) {
@@ -335,8 +370,8 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         // the buffer stays below 128 MB
         const uint32_t item_rows = split ? rows_per_block : t.nrows_padded;
         bool use_tails = item_rows <= 512 && (uint64_t)nblocks * kTailSlots * sizeof(uint64_t) <= (128ull << 20);
-        if (const char* forced = std::getenv("HAVAC_BLOCK_TAILS"))      // experiments: 0 = off, 2 = on whatever the height of an item
-            use_tails = std::atoi(forced) == 2 ? (uint64_t)nblocks * kTailSlots * sizeof(uint64_t) <= (128ull << 20) : use_tails && std::atoi(forced) != 0;
+        if (c->tune_block_tails >= 0)      // experiments: 0 = off, 1 = the default rule, 2 = on whatever the height of an item
+            use_tails = c->tune_block_tails == 2 ? (uint64_t)nblocks * kTailSlots * sizeof(uint64_t) <= (128ull << 20) : use_tails && c->tune_block_tails != 0;
         if (use_tails && c->tail_blocks < nblocks) {
             HIP_TRY(c->err, hipStreamSynchronize(stream));        // an earlier pass on this stream may still use the old buffers
             if (c->tails) (void)hipFree(c->tails);
@@ -375,6 +410,7 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     c->pending = true; c->stream = stream; c->d_hits = d_hits; c->hit_capacity = hit_capacity;
     c->row_bits = row_bits;
     c->key_bits = 14 + row_bits + seg_bits;
+    c->first_segment = col_begin / HAVAC_SEGMENT_COLUMNS; c->nsegments = (col_end - col_begin) / HAVAC_SEGMENT_COLUMNS;
     return HAVAC_OK;
 }
 
@@ -401,15 +437,10 @@ static int sort_run(havac_ssv_ctx* c, uint64_t* keys, uint64_t* alt, uint64_t co
     return HAVAC_OK;
 }
 
+static int ensure_alt(havac_ssv_ctx* c, uint64_t count);
 static int sort_keys(havac_ssv_ctx* c, uint64_t* keys, uint64_t count, hipStream_t stream, unsigned key_bits = 64) {
     if (count < 2) return HAVAC_OK;
-    if (c->sort_alt_count < count) {
-        if (c->sort_alt) (void)hipFree(c->sort_alt);
-        c->sort_alt = nullptr; c->sort_alt_count = 0;
-        size_t want = (size_t)count + count / 4 + 1024;
-        HIP_TRY(c->err, hipMalloc(&c->sort_alt, want * sizeof(uint64_t)));
-        c->sort_alt_count = want;
-    }
+    if (int rc = ensure_alt(c, count)) return rc;
     // (rocPRIM orders more than 2^32 keys in one call: 4.5e9 checked, tools/big_sort_check.py)
     int rc = sort_run(c, keys, c->sort_alt, count, stream, key_bits);
     if (rc) return rc;
@@ -417,35 +448,138 @@ static int sort_keys(havac_ssv_ctx* c, uint64_t* keys, uint64_t count, hipStream
     return HAVAC_OK;
 }
 
-extern "C" int havac_ssv_finish(havac_ssv_ctx* c, uint64_t* hit_count_out) {
+// finish = begin (wait for the count, enqueue the ordering) + end (wait for the ordering).  A caller with several contexts --
+// several GPUs behind one handle -- begins all of them before it ends any: the orderings then run side by side instead
+// of one after the other with a host wait in between.
+// ---- ordering ------------------------------------------------------------------------------------------------------------
+static int ensure_alt(havac_ssv_ctx* c, uint64_t count) {
+    if (c->sort_alt_count >= count) return HAVAC_OK;
+    if (c->sort_alt) (void)hipFree(c->sort_alt);
+    c->sort_alt = nullptr; c->sort_alt_count = 0;
+    const size_t want = (size_t)count + count / 4 + 1024;
+    HIP_TRY(c->err, hipMalloc(&c->sort_alt, want * sizeof(uint64_t)));
+    c->sort_alt_count = want;
+    return HAVAC_OK;
+}
+
+// the generic path: radix sort of the keys, then key -> record
+static int order_by_radix_sort(havac_ssv_ctx* c, uint64_t* d_hits, uint64_t count, hipStream_t stream) {
+    int rc = sort_keys(c, d_hits, count, stream, c->key_bits);
+    if (rc) return rc;
+    if (count)
+        hipLaunchKernelGGL(ssv_keys_to_records, dim3((unsigned)std::min<uint64_t>((count + 255) / 256, 1u << 20)), dim3(256), 0,
+                           stream, d_hits, count, c->row_bits);
+    return HAVAC_OK;
+}
+
+// The queue's `count` sort keys -> the reference's records in device order, on `stream` (hit_order.hip.h).  Buckets are
+// runs of consecutive key values, (key >> shift): whole segments when segments hold few records (C2: 124 each), ranges
+// of 2^k rows of a segment when they hold many (C3: 54,800 each), chosen so that a bucket holds kTargetBucket records on
+// average.  Returns with the work enqueued; finish_end() looks at the `oversized` word afterwards.
+static int order_records(havac_ssv_ctx* c, uint64_t* d_hits, uint64_t count, hipStream_t stream) {
+    c->bucket_ordered = false; c->order_count = count;
+    c->last_order_buckets = 0; c->last_order_largest = 0; c->last_order_path = 0;
+    if (count == 0) return HAVAC_OK;
+    const unsigned row_bits = c->row_bits;
+    // how many row ranges per segment: enough for kTargetBucket records per bucket on average, and enough for the low bits of
+    // a key inside a bucket to fit 32 bits (14 column bits + at most 18 row bits)
+    unsigned split_bits = 0;
+    const uint64_t per_segment = count / std::max<uint64_t>(c->nsegments, 1);
+    while (split_bits < row_bits && (per_segment >> split_bits) > kTargetBucket) split_bits++;
+    if (row_bits > 18 && split_bits < row_bits - 18) split_bits = row_bits - 18;
+    const unsigned shift = 14 + row_bits - split_bits;
+    const uint64_t nbuckets64 = c->nsegments << split_bits;
+    if (c->tune_ordering == 0 || count < 2 || nbuckets64 >= (1ull << 27)) return order_by_radix_sort(c, d_hits, count, stream);
+    const uint32_t nbuckets = (uint32_t)nbuckets64;
+    const uint64_t base = c->first_segment << split_bits;
+    int rc = ensure_alt(c, count);
+    if (rc) return rc;
+    if (c->bucket_alloc < nbuckets) {
+        HIP_TRY(c->err, hipStreamSynchronize(stream));
+        if (c->bucket_counts) (void)hipFree(c->bucket_counts);
+        if (c->bucket_offsets) (void)hipFree(c->bucket_offsets);
+        if (c->bucket_large) (void)hipFree(c->bucket_large);
+        c->bucket_counts = nullptr; c->bucket_offsets = nullptr; c->bucket_large = nullptr; c->bucket_alloc = 0;
+        const size_t want = (size_t)nbuckets + nbuckets / 4 + 1024;
+        HIP_TRY(c->err, hipMalloc(&c->bucket_counts, want * sizeof(uint32_t)));
+        HIP_TRY(c->err, hipMalloc(&c->bucket_offsets, (want + 1) * sizeof(uint64_t)));
+        HIP_TRY(c->err, hipMalloc(&c->bucket_large, want * sizeof(uint32_t)));
+        c->bucket_alloc = want;
+    }
+    HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, (size_t)nbuckets * sizeof(uint32_t), stream));
+    HIP_TRY(c->err, hipMemsetAsync(c->order_state, 0, sizeof(OrderState), stream));
+    const unsigned pass_blocks = (unsigned)std::min<uint64_t>((count + 255) / 256, (uint64_t)c->resident_blocks * 8);
+    hipLaunchKernelGGL(ssv_bucket_count, dim3(pass_blocks), dim3(256), 0, stream, (const uint64_t*)d_hits, count, shift, base, c->bucket_counts);
+    hipLaunchKernelGGL(ssv_bucket_scan, dim3(1), dim3(1024), 0, stream, c->bucket_counts, nbuckets, c->bucket_offsets, c->bucket_large, c->order_state);
+    hipLaunchKernelGGL(ssv_bucket_scatter, dim3(pass_blocks), dim3(256), 0, stream, (const uint64_t*)d_hits, count, shift, base,
+                       (const uint64_t*)c->bucket_offsets, c->bucket_counts, c->sort_alt, (const OrderState*)c->order_state);
+    hipLaunchKernelGGL(ssv_bucket_sort_small, dim3(std::min<uint32_t>(nbuckets, 1u << 30)), dim3(256), 0, stream, (const uint64_t*)c->sort_alt, d_hits,
+                       (const uint64_t*)c->bucket_offsets, nbuckets, shift, base, row_bits, (const OrderState*)c->order_state);
+    hipLaunchKernelGGL(ssv_bucket_sort_large, dim3(256), dim3(1024), 0, stream, (const uint64_t*)c->sort_alt, d_hits,
+                       (const uint64_t*)c->bucket_offsets, (const uint32_t*)c->bucket_large, shift, base, row_bits, (const OrderState*)c->order_state);
+    HIP_TRY(c->err, hipMemcpyAsync(c->h_order_state, c->order_state, sizeof(OrderState), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c->err, hipGetLastError());
+    c->bucket_ordered = true;
+    c->last_order_buckets = nbuckets;
+    return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_finish_begin(havac_ssv_ctx* c) {
     if (!c) return HAVAC_E_ARGUMENT;
     if (!c->pending) { c->err = "no pass enqueued"; return HAVAC_E_LOGIC; }
-    c->pending = false;
+    if (c->ordering) { c->err = "havac_ssv_finish_begin called twice for one pass"; return HAVAC_E_LOGIC; }
     HIP_TRY(c->err, hipSetDevice(c->device));
-    HIP_TRY(c->err, hipEventSynchronize(c->ev[4]));
+    hipError_t waited = hipEventSynchronize(c->ev[4]);
+    if (waited != hipSuccess) { c->pending = false; c->err = hip_msg("hipEventSynchronize", waited); return HAVAC_E_RUNTIME; }
     const hipStream_t order = c->order_stream ? c->order_stream : c->stream;     // the kernel is done: no device-side dependency needed
-    uint64_t found = *c->h_count;
+    c->found = *c->h_count;
     if ((uint32_t)c->h_count[1] != 0) {
+        c->pending = false;
         (void)hipMemsetAsync(c->tickets + kTicketCounters * kTicketStride, 0, sizeof(uint32_t), c->stream);
         c->err = "the SSV kernel gave up waiting for a row block of a tile (work-queue fault)";
         return HAVAC_E_RUNTIME;
     }
-    uint64_t stored = found < c->hit_capacity ? found : c->hit_capacity;
-    int rc = sort_keys(c, c->d_hits, stored, order, c->key_bits);
-    if (rc) return rc;
-    if (stored)
-        hipLaunchKernelGGL(ssv_keys_to_records, dim3((unsigned)std::min<uint64_t>((stored + 255) / 256, 1u << 20)), dim3(256), 0,
-                           order, c->d_hits, stored, c->row_bits);
+    const uint64_t stored = c->found < c->hit_capacity ? c->found : c->hit_capacity;
+    int rc = order_records(c, c->d_hits, stored, order);
+    if (rc) { c->pending = false; return rc; }
     HIP_TRY(c->err, hipEventRecord(c->ev[3], order));
-    HIP_TRY(c->err, hipStreamSynchronize(order));
+    c->ordering = true;
+    return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_finish_end(havac_ssv_ctx* c, uint64_t* hit_count_out) {
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (!c->pending || !c->ordering) { c->err = "no pass is being ordered: call havac_ssv_finish_begin first"; return HAVAC_E_LOGIC; }
+    c->pending = false; c->ordering = false;
+    HIP_TRY(c->err, hipSetDevice(c->device));
+    HIP_TRY(c->err, hipEventSynchronize(c->ev[3]));
+    c->last_order_path = c->bucket_ordered ? 1 : 0;
+    if (c->bucket_ordered) {
+        c->last_order_largest = c->h_order_state->largest;
+        if (c->h_order_state->oversized) {
+            // a bucket too big for an LDS sort: nothing was moved (hit_order.hip.h) -- this pass takes the generic path
+            const hipStream_t order = c->order_stream ? c->order_stream : c->stream;
+            int rc = order_by_radix_sort(c, c->d_hits, c->order_count, order);
+            if (rc) return rc;
+            HIP_TRY(c->err, hipEventRecord(c->ev[3], order));
+            HIP_TRY(c->err, hipEventSynchronize(c->ev[3]));
+            c->last_order_path = 2;
+        }
+    }
     HIP_TRY(c->err, hipEventElapsedTime(&c->ssv_ms, c->ev[1], c->ev[2]));
     HIP_TRY(c->err, hipEventElapsedTime(&c->total_ms, c->ev[0], c->ev[3]));
-    if (hit_count_out) *hit_count_out = found;
-    if (found > c->hit_capacity) {
-        c->err = "hit buffer overflow: " + std::to_string(found) + " hits found, capacity " + std::to_string(c->hit_capacity);
+    if (hit_count_out) *hit_count_out = c->found;
+    if (c->found > c->hit_capacity) {
+        c->err = "hit buffer overflow: " + std::to_string(c->found) + " hits found, capacity " + std::to_string(c->hit_capacity);
         return HAVAC_E_HIT_OVERFLOW;
     }
     return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_finish(havac_ssv_ctx* c, uint64_t* hit_count_out) {
+    const int rc = havac_ssv_finish_begin(c);
+    if (rc) return rc;
+    return havac_ssv_finish_end(c, hit_count_out);
 }
 
 extern "C" int havac_ssv_sort_hits(havac_ssv_ctx* c, uint64_t* d_hits, uint64_t count, void* hip_stream) {
@@ -932,14 +1066,18 @@ static int final_state(const havac_dev* d) {
     return d->failed ? HAVAC_STATE_ERROR : (d->aborted ? HAVAC_STATE_ABORT : HAVAC_STATE_COMPLETED);
 }
 
-// completes a drained run: every GPU orders its own hits
+// completes a drained run: every GPU orders its own hits -- all orderings are enqueued before any is waited for, so
+// with several GPUs behind the handle they run side by side
 static int dev_finish(havac_dev* d) {
     if (d->finished) return final_state(d);
     d->finished = true;
     d->found = 0;
-    for (DevicePart& p : d->parts) {
+    std::vector<int> begun(d->parts.size(), HAVAC_OK);
+    for (size_t i = 0; i < d->parts.size(); i++) begun[i] = havac_ssv_finish_begin(d->parts[i].ctx);
+    for (size_t i = 0; i < d->parts.size(); i++) {
+        DevicePart& p = d->parts[i];
         uint64_t found = 0;
-        int rc = havac_ssv_finish(p.ctx, &found);
+        const int rc = begun[i] != HAVAC_OK ? begun[i] : havac_ssv_finish_end(p.ctx, &found);
         p.found = found;
         d->found += found;
         if (rc != HAVAC_OK) {
@@ -1045,15 +1183,22 @@ extern "C" int havac_dev_read_hits64(havac_dev* d, uint64_t* out, uint64_t n) {
     int rc = havac_dev_num_hits64(d, &have);
     if (rc) return rc;
     if (n > have) n = have;
-    // shard order is device order: the GPUs' lists are simply laid end to end
+    // shard order is device order: the GPUs' lists are simply laid end to end -- every GPU's copy is enqueued before any is
+    // waited for, so with several GPUs behind the handle the copies cross PCIe side by side
     uint64_t at = 0;
+    std::vector<DevicePart*> copying;
     for (DevicePart& p : d->parts) {
         if (at >= n) break;
         uint64_t take = p.found < n - at ? p.found : n - at;
         if (take == 0) continue;
         HIP_TRY(d->err, hipSetDevice(p.device));
-        HIP_TRY(d->err, hipMemcpy(out + at, p.d_hits, (size_t)take * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(d->err, hipMemcpyAsync(out + at, p.d_hits, (size_t)take * sizeof(uint64_t), hipMemcpyDeviceToHost, p.stream));
+        copying.push_back(&p);
         at += take;
+    }
+    for (DevicePart* p : copying) {
+        HIP_TRY(d->err, hipSetDevice(p->device));
+        HIP_TRY(d->err, hipStreamSynchronize(p->stream));
     }
     return HAVAC_OK;
 }

@@ -51,6 +51,25 @@ class SsvContext:
         self._check(self._L.havac_ssv_finish(self._h, C.byref(n)))
         return n.value
 
+    def finish_begin(self):
+        """first half of finish(): waits for the hit count, enqueues the ordering (begin all contexts, then end all)"""
+        self._check(self._L.havac_ssv_finish_begin(self._h))
+
+    def finish_end(self) -> int:
+        n = C.c_uint64(0)
+        self._check(self._L.havac_ssv_finish_end(self._h, C.byref(n)))
+        return n.value
+
+    def set_tuning(self, rows_per_block: int = -1, tiles_per_item: int = -1, block_tails: int = -1, ordering: int = -1):
+        """experiment knobs of the next passes (include/havac_dev.h: havac_ssv_set_tuning); -1 = the library's own rule"""
+        self._check(self._L.havac_ssv_set_tuning(self._h, rows_per_block, tiles_per_item, block_tails, ordering))
+
+    def last_ordering(self):
+        """-> (path, buckets, largest bucket) of the last finished pass: path 0 radix sort, 1 bucket ordering, 2 fallback"""
+        path, nb, big = C.c_int(0), C.c_uint32(0), C.c_uint32(0)
+        self._check(self._L.havac_ssv_last_ordering(self._h, C.byref(path), C.byref(nb), C.byref(big)))
+        return path.value, nb.value, big.value
+
     def sort_hits(self, d_hits: int, count: int, stream: int = 0):
         self._check(self._L.havac_ssv_sort_hits(self._h, d_hits, count, stream or None))
 

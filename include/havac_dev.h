@@ -252,11 +252,30 @@ int havac_ssv_set_cell_trace(havac_ssv_ctx *ctx, havac_cell_record *d_cells, uin
                              uint32_t nrows, uint32_t ncols);
 
 /* Completes the enqueued pass: waits for it, puts the shard's records in
- * d_hits into device order (radix sort on the enqueue's stream, or on the
+ * d_hits into device order (on the enqueue's stream, or on the
  * ordering stream set above) and returns the
  * number of hits found.  If that exceeds hit_capacity only hit_capacity
  * records were kept and the result is HAVAC_E_HIT_OVERFLOW. */
 int havac_ssv_finish(havac_ssv_ctx *ctx, uint64_t *hit_count_out);
+
+/* havac_ssv_finish in two halves, for a caller with several contexts (several GPUs): _begin waits for the pass's hit count
+ * and ENQUEUES the ordering, _end waits for the ordering and returns what havac_ssv_finish returns.  Begin all contexts,
+ * then end all: the orderings run side by side instead of one after the other with a host wait in between
+ * (havac_dev_wait does exactly this over the GPUs of a handle).  havac_ssv_finish = _begin + _end. */
+int havac_ssv_finish_begin(havac_ssv_ctx *ctx);
+int havac_ssv_finish_end(havac_ssv_ctx *ctx, uint64_t *hit_count_out);
+
+/* Experiment knobs of the next passes (tools/, tests/): how the launch hands out work and how the records are ordered.
+ * Every value: -1 = the library's own rule (the default).
+ *   rows_per_block  rows of a row block (a multiple of 1024); 0 = never cut tiles into row blocks
+ *   tiles_per_item  adjacent tiles a wave walks (>= 1; short models)
+ *   block_tails     0 = never, 1 = the default rule, 2 = whatever the height of an item
+ *   ordering        0 = always the generic radix sort, 1 = the bucket ordering (the default)
+ * No counterpart in the reference. */
+int havac_ssv_set_tuning(havac_ssv_ctx *ctx, int rows_per_block, int tiles_per_item, int block_tails, int ordering);
+/* How the last finished pass was ordered: *path = 0 radix sort, 1 bucket ordering, 2 bucket ordering given up for the
+ * radix sort (a bucket too big for an LDS sort); the number of buckets and the largest one. */
+int havac_ssv_last_ordering(havac_ssv_ctx *ctx, int *path, uint32_t *nbuckets, uint32_t *largest_bucket);
 
 /* Sort `count` packed records in place into device order (for callers that merge
  * lists from elsewhere; the shards of havac_ssv_enqueue need no sorting, see above). */

@@ -14,10 +14,13 @@ def torch_dev():
     return torch, torch.device("cuda", 0)
 
 
-def run_shards(torch, dev, packed, model, world=1, capacity=1 << 22):
-    """-> list of per-shard device-ordered record arrays (numpy uint64)"""
+def run_shards(torch, dev, packed, model, world=1, capacity=1 << 22, tuning=None, orderings=None):
+    """-> list of per-shard device-ordered record arrays (numpy uint64); `tuning` = keyword arguments of
+    SsvContext.set_tuning; `orderings` (a list) receives last_ordering() of every shard's pass"""
     from havac_amd.ssv import SsvContext
     ctx = SsvContext()
+    if tuning:
+        ctx.set_tuning(**tuning)
     d_seq = torch.from_numpy(packed).to(dev)
     d_phmm = torch.from_numpy(np.ascontiguousarray(model).reshape(-1)).to(dev)
     hits = torch.empty(capacity, dtype=torch.int64, device=dev)
@@ -27,6 +30,8 @@ def run_shards(torch, dev, packed, model, world=1, capacity=1 << 22):
         ctx.enqueue(d_seq.data_ptr(), packed.size * 4, d_phmm.data_ptr(), model.shape[0], hits.data_ptr(), capacity, r, world, 0, stream)
         n = ctx.finish()
         out.append(hits[:n].cpu().numpy().view(np.uint64).copy())
+        if orderings is not None:
+            orderings.append(ctx.last_ordering())
     ctx.close()
     return out
 
@@ -324,11 +329,11 @@ def test_short_models_whole_hit_list(torch_dev, oracle, nrows):
 
 
 @pytest.mark.parametrize("per_item", [2, 3, 8])
-def test_tiles_per_item_forced_on_small_problems(torch_dev, oracle, per_item, monkeypatch):
+def test_tiles_per_item_forced_on_small_problems(torch_dev, oracle, per_item):
     """the same path on small, ragged problems (tile counts that are no multiple of the group, one-row models, the
-    matrix's edges inside a group): HAVAC_TILES_PER_ITEM forces the grouping the launch would only choose for big inputs"""
+    matrix's edges inside a group): havac_ssv_set_tuning forces the grouping (off by default, kept for experiments)"""
     torch, dev = torch_dev
-    monkeypatch.setenv("HAVAC_TILES_PER_ITEM", str(per_item))
+    tuning = dict(tiles_per_item=per_item)
     rng = np.random.default_rng(per_item)
     for case in range(12):
         nrows = int(rng.choice([1, 2, 31, 32, 33, 64, 100, 128, 300]))
@@ -339,25 +344,25 @@ def test_tiles_per_item_forced_on_small_problems(torch_dev, oracle, per_item, mo
         else:
             model, cons = synth.dfam_like_model(nrows, 60 + case)
             synth.plant_homologs(sym, cons, sym.size, every=900, length=min(nrows, 150), sub=0.08)
-        got, = run_shards(torch, dev, synth.pack_2bit(sym), model, capacity=1 << 23)
+        got, = run_shards(torch, dev, synth.pack_2bit(sym), model, capacity=1 << 23, tuning=tuning)
         want = oracle.ssv(sym, model, cap=1 << 23)
         assert np.array_equal(got, want), (per_item, case, nrows, nseg, got.size, want.size)
     # and sharded: every shard groups its own tiles
     sym = synth.random_symbols(9 * synth.SEGMENT, 99)
     model, cons = synth.dfam_like_model(64, 98)
     synth.plant_homologs(sym, cons, sym.size, every=700, length=60, sub=0.05)
-    parts = run_shards(torch, dev, synth.pack_2bit(sym), model, world=4)
+    parts = run_shards(torch, dev, synth.pack_2bit(sym), model, world=4, tuning=tuning)
     assert np.array_equal(np.concatenate(parts), oracle.ssv(sym, model))
 
 
-@pytest.mark.parametrize("tails", ["0", "1", "2"])
-def test_block_tails_on_and_off(torch_dev, oracle, tails, monkeypatch):
+@pytest.mark.parametrize("tails", [0, 1, 2])
+def test_block_tails_on_and_off(torch_dev, oracle, tails):
     """What a block still has staged at its end leaves through a side buffer and a gather kernel (block tails: the default for
-    items of up to 512 rows, HAVAC_BLOCK_TAILS=2 forces them for taller ones) or with one returning atomic per block
-    (HAVAC_BLOCK_TAILS=0, tall items, launches too big for a side buffer): the same lists either way, on sparse hits (every tail fits), dense hits (tails that overflow their 128 slots
+    items of up to 512 rows, havac_ssv_set_tuning(block_tails=2) forces them for taller ones) or with one returning atomic per block
+    (block_tails=0, tall items, launches too big for a side buffer): the same lists either way, on sparse hits (every tail fits), dense hits (tails that overflow their 128 slots
     fall back to the atomic) and a short model x 100 Mbp."""
     torch, dev = torch_dev
-    monkeypatch.setenv("HAVAC_BLOCK_TAILS", tails)
+    tuning = dict(block_tails=tails)
     rng = np.random.default_rng(17)
     for case in range(8):
         nrows = int(rng.choice([1, 32, 64, 100, 1000, 3000]))
@@ -368,11 +373,64 @@ def test_block_tails_on_and_off(torch_dev, oracle, tails, monkeypatch):
         else:
             model, cons = synth.dfam_like_model(nrows, 600 + case)
             synth.plant_homologs(sym, cons, sym.size, every=800, length=min(nrows, 200), sub=0.08)
-        got, = run_shards(torch, dev, synth.pack_2bit(sym), model, capacity=1 << 24)
+        got, = run_shards(torch, dev, synth.pack_2bit(sym), model, capacity=1 << 24, tuning=tuning)
         want = oracle.ssv(sym, model, cap=1 << 24)
         assert np.array_equal(got, want), (tails, case, nrows, nseg, got.size, want.size)
     ncols = 100_012_032
     model, cons = synth.dfam_like_model(48, 4300)
     packed = synth.random_packed(ncols, 4301)
-    got, = run_shards(torch, dev, packed, model)
+    got, = run_shards(torch, dev, packed, model, tuning=tuning)
     assert np.array_equal(got, whole_list(oracle, packed, model))
+
+
+def test_ordering_by_buckets_equals_radix_sort_and_the_checker(torch_dev, oracle):
+    """hit_order.hip.h: the records are put in the FPGA's emission order (device/HavacHls.cpp:151-152,264;
+    device/HitReporting.cpp:178-337) by bucketing on (segment, row range) and sorting every bucket in LDS.  Whatever the
+    shape -- one bucket per segment (short models), row ranges (tall ones), small and large buckets, shards, a single
+    record, none -- the list equals the checker's element for element, and the radix sort's (ordering=0)."""
+    torch, dev = torch_dev
+    rng = np.random.default_rng(31)
+    seen_paths, largest_seen = set(), 0
+    for case in range(14):
+        nrows = int(rng.choice([1, 40, 300, 1024, 5000, 20000]))
+        nseg = int(rng.integers(1, 30))
+        sym = synth.random_symbols(nseg * synth.SEGMENT, 900 + case)
+        kind = case % 4
+        if kind == 0:
+            model = rng.integers(-110, 128, size=(nrows, 4)).astype(np.int8)                # dense: large buckets
+        elif kind == 1:
+            model = np.full((nrows, 4), -128, np.int8)                                      # nothing hits
+            if case == 1:
+                model[: min(nrows, 3)] = 127                                                # ... or every cell of row 2 does
+        else:
+            model, cons = synth.dfam_like_model(nrows, 700 + case)
+            synth.plant_homologs(sym, cons, sym.size, every=1500, length=min(nrows, 250), sub=0.08)
+        packed = synth.pack_2bit(sym)
+        want = oracle.ssv_mt(sym, model, cap=1 << 25)
+        for world in (1, 3):
+            if world > nseg:
+                continue
+            orderings = []
+            by_buckets = run_shards(torch, dev, packed, model, world=world, capacity=1 << 25, orderings=orderings)
+            by_radix = run_shards(torch, dev, packed, model, world=world, capacity=1 << 25, tuning=dict(ordering=0))
+            assert np.array_equal(np.concatenate(by_buckets), want), (case, world, nrows, nseg, want.size)
+            assert all(np.array_equal(a, b) for a, b in zip(by_buckets, by_radix))
+            seen_paths.update(path for path, _, _ in orderings)
+            largest_seen = max([largest_seen] + [big for _, _, big in orderings])
+    assert 1 in seen_paths                      # the bucket ordering really ran
+    assert largest_seen > 2048                  # ... through its large-bucket sorter too
+
+
+def test_ordering_gives_up_on_a_bucket_too_big_for_lds(torch_dev, oracle):
+    """One model of a sparse collection that hits everywhere: its buckets hold far more than the launch's average and
+    more than an LDS sort takes (16,384 records); the pass then falls back to the radix sort -- same list."""
+    torch, dev = torch_dev
+    quiet = np.full((6000, 4), -128, np.int8)
+    hot = np.full((40, 4), 127, np.int8)                          # every cell of 38 rows x all columns hits every third row
+    model = np.concatenate([quiet[:3000], hot, quiet[3000:]])
+    sym = synth.random_symbols(40 * synth.SEGMENT, 77)
+    orderings = []
+    got, = run_shards(torch, dev, synth.pack_2bit(sym), model, capacity=1 << 25, orderings=orderings)
+    want = oracle.ssv_mt(sym, model, cap=1 << 25)
+    assert want.size > 1_000_000 and np.array_equal(got, want)
+    assert orderings[0][0] == 2 and orderings[0][2] > 16384      # given up for the radix sort; the largest bucket said why
