@@ -302,6 +302,8 @@ def main():
                          "0 = 3 for passes up to 1e12 cells per GPU (C2 is 1e11), else 1: ordering tens of millions of "
                          "records next to the following kernel slows that kernel by more than it hides "
                          "(C3 shape: 303 vs 267 ms per step)")
+    ap.add_argument("--tuning", default="", help="experiments: rows_per_block,tiles_per_item,block_tails,ordering for "
+                    "havac_ssv_set_tuning (-1 = the library's own rule), e.g. --tuning=-1,-1,-1,0 orders with the radix sort")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--pmc-timeout", type=int, default=240)
@@ -364,7 +366,8 @@ def main():
     # records per cell: 1.0e-5 on C2, 0.9e-5 on the collection
     hit_capacity = max(1 << 20, int(my_cells * (4e-5 if my_cells <= 1e13 else 1.2e-5)))
     depth = args.pipeline_depth if args.pipeline_depth > 0 else (3 if my_cells <= 1e12 else 1)
-    engine = ShardedSsv(hit_capacity, device, depth=depth, gather_when_alone=use_dist)
+    tuning = [int(v) for v in args.tuning.split(",")] if args.tuning else None
+    engine = ShardedSsv(hit_capacity, device, depth=depth, gather_when_alone=use_dist, tuning=tuning)
 
     def fence():
         if use_dist:
@@ -400,7 +403,7 @@ def main():
     if depth > 1:       # the same steps strictly one after the other, for the record (not `value`)
         if rank == 0 and merged is not None:
             merged = merged.clone()
-        serial = ShardedSsv(hit_capacity, device, depth=1, gather_when_alone=use_dist)
+        serial = ShardedSsv(hit_capacity, device, depth=1, gather_when_alone=use_dist, tuning=tuning)
         run_steps(serial, 2)
         fence()
         t1 = time.perf_counter()

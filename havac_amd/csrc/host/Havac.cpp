@@ -9,6 +9,7 @@
 #include <stdexcept>
 
 #include "../../../include/havac_dev.h"
+#include "HostThreads.hpp"
 #include "PhmmPreprocessor.hpp"
 #include "SequencePreprocessor.hpp"
 
@@ -41,6 +42,18 @@ Havac::Havac(const std::vector<uint32_t> &deviceIndices, const float requiredPVa
     init();
 }
 
+Havac::Havac(DeferredStart, const uint32_t deviceIndex, const float requiredPValue)
+    : deviceIndex(deviceIndex), requiredPValue(requiredPValue) {
+    init();
+    deviceStart_ = std::thread([this, deviceIndex] { deviceStartCode_ = havac_dev_create(deviceIndex, &dev_); });
+}
+
+void Havac::needDevice() {
+    if (deviceStart_.joinable()) deviceStart_.join();
+    if (deviceStartCode_ == HAVAC_E_NOMEM) throw std::bad_alloc();
+    if (deviceStartCode_ != HAVAC_OK) throw std::runtime_error("ERROR: could not open MI355X device " + std::to_string(deviceIndex));
+}
+
 void Havac::init() {
     fastaVector = static_cast<FastaVector *>(std::malloc(sizeof(FastaVector)));
     p7HmmList = static_cast<P7HmmList *>(std::calloc(1, sizeof(P7HmmList)));
@@ -52,6 +65,7 @@ void Havac::init() {
 }
 
 Havac::~Havac() {
+    if (deviceStart_.joinable()) deviceStart_.join();
     fastaVectorDealloc(fastaVector);
     p7HmmListDealloc(p7HmmList);
     std::free(fastaVector);
@@ -70,6 +84,7 @@ void Havac::loadPhmm(const std::string phmmSrc) {
     PhmmPreprocessor preprocessor(p7HmmList, requiredPValue, boundaryMode_);
     compressedPhmmScores = preprocessor.getProcessedPhmmData();
     modelStarts_ = preprocessor.getModelStarts();
+    needDevice();
     check(havac_dev_write_phmm(dev_, compressedPhmmScores->data(), compressedPhmmScores->size()));
     phmmLoadedToDevice = true;
 }
@@ -84,6 +99,7 @@ void Havac::loadSequence(const std::string fastaSrc) {
         vector<uint64_t> ends, starts, residues;
         for (size_t j = 0; j < fastaVector->metadata.count; j++) ends.push_back(fastaVector->metadata.data[j].sequenceEndPosition);
         if (boundaryMode_) {
+            needDevice();
             // every record its own columns + a separator pair, a/c/g as they are, everything else T (no rand())
             recordStarts_.assign(ends.size(), 0);
             check(havac_dev_write_sequence_records(dev_, fastaVector->sequence.charData, fastaVector->sequence.count, ends.data(),
@@ -96,6 +112,7 @@ void Havac::loadSequence(const std::string fastaSrc) {
             vector<uint64_t> patchColumns;
             vector<uint8_t> patchSymbols;
             SequencePreprocessor::collectPatches(fastaVector, patchColumns, patchSymbols);
+            needDevice();
             check(havac_dev_write_sequence_chars(dev_, fastaVector->sequence.charData, fastaVector->sequence.count,
                                                  patchColumns.data(), patchSymbols.data(), patchColumns.size()));
         }
@@ -123,6 +140,7 @@ void Havac::loadSequence(const std::string fastaSrc) {
         residueCounts_ = residues;
     }
     vector<uint8_t> &packed = preprocessor.getCompressedSequenceBuffer();
+    needDevice();
     check(havac_dev_write_sequence(dev_, packed.data(), packed.size()));
     if (boundaryMode_) {
         vector<uint8_t> &mask = preprocessor.getSeparatorMask();
@@ -143,14 +161,16 @@ void Havac::runHardwareClientAsync() {
         throw std::logic_error("Phmm was not loaded to device before hardware was requested to run.");
     if (!sequenceLoadedToDevice)   // :89-91
         throw std::logic_error("Sequence was not loaded to device before hardware was requested to run.");
+    needDevice();
     check(havac_dev_run_async(dev_));
 }
 
-void Havac::waitHardwareClientAsync() { check(havac_dev_wait(dev_, 0)); }
+void Havac::waitHardwareClientAsync() { needDevice(); check(havac_dev_wait(dev_, 0)); }
 
-void Havac::abortHardwareClient() { check(havac_dev_abort(dev_)); }
+void Havac::abortHardwareClient() { needDevice(); check(havac_dev_abort(dev_)); }
 
 enum havac_cmd_state Havac::currentHardwareState() {
+    needDevice();
     int s = havac_dev_state(dev_);
     check(s);
     return (havac_cmd_state)s;
@@ -172,9 +192,10 @@ void Havac::setBothStrands(bool on) {
     bothStrands_ = on;
 }
 
-void Havac::setHitCapacity(uint64_t maxHits) { check(havac_dev_set_hit_capacity(dev_, maxHits)); }
+void Havac::setHitCapacity(uint64_t maxHits) { needDevice(); check(havac_dev_set_hit_capacity(dev_, maxHits)); }
 
 void Havac::lastRunMilliseconds(float *ssvKernelMs, float *totalMs) {
+    needDevice();
     check(havac_dev_last_run_ms(dev_, ssvKernelMs, totalMs));
 }
 
@@ -198,32 +219,56 @@ PhmmLocalPosition phmmPrefixSumsBinarySearch(uint32_t phmmGlobalPosition, vector
     return p;
 }
 
-vector<HavacHit> havacResolveHits(const vector<uint64_t> &rawHits, const FastaVector *fastaVector,
-                                  vector<uint32_t> &phmmPrefixSums) {
-    vector<HavacHit> out;
-    out.reserve(rawHits.size());
-    for (size_t i = 0; i < rawHits.size(); i++) {
-        const uint64_t rec = rawHits[i];
-        // [13:0] column in segment, [39:14] segment, [63:40] row (host/Havac.cpp:155-163)
-        const uint64_t inSegment = rec & ((1ull << 14) - 1);
-        const uint64_t segment = (rec & ((1ull << 40) - 1)) >> 14;
-        const uint64_t globalSequencePosition = segment * (12 * 1024) + inSegment;
-        const uint32_t globalPhmmPosition = (uint32_t)(rec >> 40);
-        FastaVectorLocalPosition local;
-        if (!fastaVectorGetLocalSequencePositionFromGlobal(fastaVector, globalSequencePosition, &local))
-            continue;   // a hit in the padding after the last record (host/Havac.cpp:169-173)
-        PhmmLocalPosition where = phmmPrefixSumsBinarySearch(globalPhmmPosition, phmmPrefixSums);
-        if (where.phmmIndex == -1) {
-            std::cerr << "ERROR: could not resolve phmm position for raw hit report #" << i << "\n" << std::endl;
-            continue;
-        }
-        out.push_back(HavacHit(local.positionInSequence, (uint32_t)local.sequenceIndex, where.phmmPosition,
-                               (uint32_t)where.phmmIndex));
+// One raw record -> a HavacHit (host/Havac.cpp:150-184); false: a hit in the padding after the last record, dropped.
+static bool resolveOne(uint64_t rec, size_t index, const FastaVector *fastaVector, vector<uint32_t> &phmmPrefixSums, HavacHit *out) {
+    // [13:0] column in segment, [39:14] segment, [63:40] row (host/Havac.cpp:155-163)
+    const uint64_t inSegment = rec & ((1ull << 14) - 1);
+    const uint64_t segment = (rec & ((1ull << 40) - 1)) >> 14;
+    const uint64_t globalSequencePosition = segment * (12 * 1024) + inSegment;
+    const uint32_t globalPhmmPosition = (uint32_t)(rec >> 40);
+    FastaVectorLocalPosition local;
+    if (!fastaVectorGetLocalSequencePositionFromGlobal(fastaVector, globalSequencePosition, &local))
+        return false;   // a hit in the padding after the last record (host/Havac.cpp:169-173)
+    PhmmLocalPosition where = phmmPrefixSumsBinarySearch(globalPhmmPosition, phmmPrefixSums);
+    if (where.phmmIndex == -1) {
+        std::cerr << "ERROR: could not resolve phmm position for raw hit report #" << index << "\n" << std::endl;
+        return false;
     }
+    *out = HavacHit(local.positionInSequence, (uint32_t)local.sequenceIndex, where.phmmPosition, (uint32_t)where.phmmIndex);
+    return true;
+}
+
+// fn(i, &hit) -> keep? for every i in [0, n), results in index order.  Lists of a run hold 10^5 ... 10^9 records and every
+// record resolves on its own: long lists are cut into stretches resolved side by side on the host's cores.
+template <class F>
+static vector<HavacHit> resolveAll(size_t n, F &&fn) {
+    const size_t kStretch = 1 << 15;
+    const size_t stretches = (n + kStretch - 1) / kStretch;
+    vector<vector<HavacHit>> parts(stretches);
+    havacParallelFor(stretches, n < 4 * kStretch ? 1u : havacHostThreads(stretches), [&](size_t s) {
+        const size_t begin = s * kStretch, end = std::min(n, begin + kStretch);
+        vector<HavacHit> &mine = parts[s];
+        mine.reserve(end - begin);
+        HavacHit hit(0, 0, 0, 0);
+        for (size_t i = begin; i < end; i++)
+            if (fn(i, &hit)) mine.push_back(hit);
+    });
+    if (stretches == 1) return std::move(parts[0]);
+    size_t total = 0;
+    for (const auto &p : parts) total += p.size();
+    vector<HavacHit> out;
+    out.reserve(total);
+    for (const auto &p : parts) out.insert(out.end(), p.begin(), p.end());
     return out;
 }
 
+vector<HavacHit> havacResolveHits(const vector<uint64_t> &rawHits, const FastaVector *fastaVector,
+                                  vector<uint32_t> &phmmPrefixSums) {
+    return resolveAll(rawHits.size(), [&](size_t i, HavacHit *hit) { return resolveOne(rawHits[i], i, fastaVector, phmmPrefixSums, hit); });
+}
+
 vector<HavacHit> Havac::getHitsFromFinishedRun() {
+    needDevice();
     uint64_t n = 0;                                        // 64-bit: several GPUs can hold more than 2^32 - 1 records
     check(havac_dev_num_hits64(dev_, &n));
     rawHits_.assign(n, 0);
@@ -249,36 +294,27 @@ vector<HavacHit> Havac::getHitsFromFinishedRun() {
     };
     if (!boundaryMode_) {
         vector<uint32_t> sums = generatePhmmLenPrefixSums();
-        vector<HavacHit> out;
-        out.reserve(forward.size());
-        vector<uint64_t> one(1);
-        for (size_t i = 0; i < forward.size(); i++) {      // one at a time: havacResolveHits may drop padding hits
-            one[0] = forward[i];
-            vector<HavacHit> r = havacResolveHits(one, fastaVector, sums);
-            if (r.empty()) continue;
-            mirror(r[0], reverse[i]);
-            out.push_back(r[0]);
-        }
-        return out;
+        return resolveAll(forward.size(), [&](size_t i, HavacHit *hit) {
+            if (!resolveOne(forward[i], i, fastaVector, sums, hit)) return false;
+            mirror(*hit, reverse[i]);
+            return true;
+        });
     }
     // boundary mode: records and models have their own start tables (separators in between)
-    vector<HavacHit> out;
-    out.reserve(rawHits_.size());
-    for (size_t i = 0; i < forward.size(); i++) {
+    return resolveAll(forward.size(), [&](size_t i, HavacHit *hit) {
         const uint64_t rec = forward[i];
         const uint64_t column = ((rec >> 14) & 0x3ffffffull) * 12288ull + (rec & 0x3fffull);
         const uint32_t row = (uint32_t)(rec >> 40);
         size_t j = std::upper_bound(recordStarts_.begin(), recordStarts_.end(), column) - recordStarts_.begin();
         size_t k = std::upper_bound(modelStarts_.begin(), modelStarts_.end(), row) - modelStarts_.begin();
-        if (j == 0 || k == 0) continue;
+        if (j == 0 || k == 0) return false;
         j--; k--;
-        if (column - recordStarts_[j] >= recordLengths_[j]) continue;                     // separator or padding column
-        if (row - modelStarts_[k] >= p7HmmList->phmms[k].header.modelLength) continue;    // separator row
-        HavacHit h(column - recordStarts_[j], (uint32_t)j, row - modelStarts_[k], (uint32_t)k);
-        mirror(h, reverse[i]);
-        out.push_back(h);
-    }
-    return out;
+        if (column - recordStarts_[j] >= recordLengths_[j]) return false;                     // separator or padding column
+        if (row - modelStarts_[k] >= p7HmmList->phmms[k].header.modelLength) return false;    // separator row
+        *hit = HavacHit(column - recordStarts_[j], (uint32_t)j, row - modelStarts_[k], (uint32_t)k);
+        mirror(*hit, reverse[i]);
+        return true;
+    });
 }
 
 vector<HavacWindow> havacMergeHitsToWindows(const vector<HavacHit> &hits, const vector<uint32_t> &modelLengths,

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "FastaVector.h"
@@ -72,6 +73,13 @@ public:
     // addition: one object over several GPUs of a node, one column shard each (the reference has one deviceIndex per
     // object); everything else behaves the same, getHitsFromFinishedRun returns the same list in the same order
     Havac(const std::vector<uint32_t> &deviceIndices, const float requiredPValue = 0.02f);
+    // addition: the same object with the device layer starting on a helper thread.  Starting the HIP runtime takes
+    // ~0.1 s whatever is asked of it; with this constructor that time runs under the caller's next calls -- loadPhmm and
+    // loadSequence read and prepare their files on the host first and wait for the device only when they have something
+    // to send.  A device that cannot be opened surfaces from the first call that needs it, as the exception the
+    // reference-shaped constructor would have thrown (std::runtime_error / std::bad_alloc).
+    struct DeferredStart {};
+    Havac(DeferredStart, const uint32_t deviceIndex = 0, const float requiredPValue = 0.02f);
     Havac(Havac &&havac) = delete;
     Havac(Havac &havac) = delete;
     ~Havac();
@@ -108,6 +116,9 @@ public:
 private:
     void check(int code);                                  // C-ABI code -> the reference's exception types
     void init();
+    void needDevice();                                     // joins a deferred start; throws what the constructor would have
+    std::thread deviceStart_;
+    int deviceStartCode_ = 0;
     vector<uint32_t> generatePhmmLenPrefixSums();
 
     havac_dev *dev_ = nullptr;

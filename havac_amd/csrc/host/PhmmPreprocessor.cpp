@@ -4,6 +4,7 @@
 #include <stdexcept>
 #include <string>
 
+#include "HostThreads.hpp"
 #include "PhmmReprojection.h"
 
 // The tables are [row][A,C,G,T] (host/phmm/PhmmPreprocessor.cpp:15 allocates rows * 4), but the projection writes
@@ -20,11 +21,18 @@ PhmmPreprocessor::PhmmPreprocessor(P7HmmList *phmmList, const float desiredPvalu
     requireNucleotideModels(phmmList);
     for (uint32_t i = 0; i < phmmList->count; i++) rows_ += phmmList->phmms[i].header.modelLength;
     data_ = std::make_shared<std::vector<int8_t>>((size_t)rows_ * 4);
-    size_t at = 0;
-    for (uint32_t i = 0; i < phmmList->count; i++) {
-        p7HmmProjectForThreshold256(&phmmList->phmms[i], desiredPvalue, data_->data() + at);
-        at += (size_t)phmmList->phmms[i].header.modelLength * 4;
-    }
+    std::vector<size_t> at(phmmList->count, 0);
+    for (uint32_t i = 1; i < phmmList->count; i++) at[i] = at[i - 1] + (size_t)phmmList->phmms[i - 1].header.modelLength * 4;
+    projectAll(phmmList, desiredPvalue, at);
+}
+
+// every model is projected on its own (host/phmm/PhmmPreprocessor.cpp:21-30): side by side on the host's cores
+void PhmmPreprocessor::projectAll(P7HmmList *phmmList, const float desiredPvalue, const std::vector<size_t> &byteOffsets) {
+    int8_t *const out = data_->data();
+    const unsigned threads = rows_ < 4096 ? 1u : havacHostThreads(phmmList->count);
+    havacParallelFor(phmmList->count, threads, [&](size_t i) {
+        p7HmmProjectForThreshold256(&phmmList->phmms[i], desiredPvalue, out + byteOffsets[i]);
+    });
 }
 
 PhmmPreprocessor::PhmmPreprocessor(P7HmmList *phmmList, const float desiredPvalue, bool boundaryMode) {
@@ -35,6 +43,7 @@ PhmmPreprocessor::PhmmPreprocessor(P7HmmList *phmmList, const float desiredPvalu
         rows_ += phmmList->phmms[i].header.modelLength + gap;
     }
     data_ = std::make_shared<std::vector<int8_t>>((size_t)rows_ * 4, (int8_t)-128);   // separator rows stay -128
-    for (uint32_t i = 0; i < phmmList->count; i++)
-        p7HmmProjectForThreshold256(&phmmList->phmms[i], desiredPvalue, data_->data() + (size_t)modelStarts_[i] * 4);
+    std::vector<size_t> at(phmmList->count, 0);
+    for (uint32_t i = 0; i < phmmList->count; i++) at[i] = (size_t)modelStarts_[i] * 4;
+    projectAll(phmmList, desiredPvalue, at);
 }

@@ -3,6 +3,7 @@
 #ifndef HAVAC_PHMM_PREPROCESSOR_HPP
 #define HAVAC_PHMM_PREPROCESSOR_HPP
 
+#include <cstddef>
 #include <cstdint>
 #include <memory>
 #include <vector>
@@ -24,6 +25,7 @@ public:
     uint32_t getPhmmListLengthInVectors() const { return rows_; }
 
 private:
+    void projectAll(P7HmmList *phmmList, const float desiredPvalue, const std::vector<size_t> &byteOffsets);
     std::shared_ptr<std::vector<int8_t>> data_;
     uint32_t rows_ = 0;
     std::vector<uint32_t> modelStarts_;

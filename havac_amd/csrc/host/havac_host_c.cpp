@@ -60,6 +60,17 @@ int havac_host_create(uint32_t device_index, float p, havac_host **out) {
     return HAVAC_OK;
 }
 
+int havac_host_create_deferred(uint32_t device_index, float p, havac_host **out) {
+    if (!out) return HAVAC_E_ARGUMENT;
+    *out = nullptr;
+    havac_host *h = new (std::nothrow) havac_host;
+    if (!h) return HAVAC_E_NOMEM;
+    int rc = guarded(h, [&] { h->obj = new Havac(Havac::DeferredStart{}, device_index, p); });
+    if (rc != HAVAC_OK) { delete h; return rc; }
+    *out = h;
+    return HAVAC_OK;
+}
+
 int havac_host_create_multi(const uint32_t *devices, uint32_t n, float p, havac_host **out) {
     if (!out || !devices || n == 0) return HAVAC_E_ARGUMENT;
     *out = nullptr;
@@ -252,6 +263,23 @@ int havac_host_project_hmm(const char *path, float p, int8_t *out, uint64_t cap,
     if (nmodels) *nmodels = list.count;
     for (uint32_t i = 0; lengths && i < list.count && i < lengths_cap; i++) lengths[i] = list.phmms[i].header.modelLength;
     if (out && cap >= data->size()) std::memcpy(out, data->data(), data->size());
+    p7HmmListDealloc(&list);
+    return HAVAC_OK;
+}
+
+int havac_host_read_hmm_emissions(const char *path, float *out, uint64_t cap, uint64_t *nvalues, uint32_t *nmodels) {
+    P7HmmList list;
+    P7HmmReturnCode rc = readP7Hmm(path, &list);
+    if (rc == p7HmmAllocationFailure) return HAVAC_E_NOMEM;
+    if (rc != p7HmmSuccess) return HAVAC_E_RUNTIME;
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < list.count; i++) {
+        const uint64_t n = (uint64_t)list.phmms[i].header.modelLength * p7HmmGetAlphabetCardinality(&list.phmms[i]);
+        for (uint64_t k = 0; k < n; k++, at++)
+            if (out && at < cap) out[at] = list.phmms[i].model.matchEmissionScores[k];
+    }
+    if (nvalues) *nvalues = at;
+    if (nmodels) *nmodels = list.count;
     p7HmmListDealloc(&list);
     return HAVAC_OK;
 }

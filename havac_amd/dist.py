@@ -106,13 +106,17 @@ class ShardedSsv:
     The records ``collect`` returns live in the slot's receive buffer (world > 1) or hit buffer (world == 1): they
     are valid until that slot is submitted again, and the caller's current stream has been made to wait for them."""
 
-    def __init__(self, hit_capacity: int, device: torch.device, depth: int = 1, gather_when_alone: bool = False):
+    def __init__(self, hit_capacity: int, device: torch.device, depth: int = 1, gather_when_alone: bool = False, tuning=None):
+        """tuning: optional (rows_per_block, tiles_per_item, block_tails, ordering) for SsvContext.set_tuning (experiments)"""
         self.device = device
         # rehearsals on one GPU: run the collectives even in a one-rank group
         self.gather_when_alone = gather_when_alone and dist.is_initialized()
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.slots = [_Slot(hit_capacity, device, depth > 1) for _ in range(max(1, depth))]
+        if tuning:
+            for slot in self.slots:
+                slot.ctx.set_tuning(*tuning)
         _low, high = torch.cuda.Stream.priority_range()
         self.kernel_stream = torch.cuda.Stream(device, priority=high) if depth > 1 else None
         self.in_flight = []               # slot indices, oldest first

@@ -22,6 +22,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "libhavac.so")
 _vp = C.c_void_p
 HOST_SIGNATURES = {
     "havac_host_create": (C.c_int, [C.c_uint32, C.c_float, C.POINTER(C.c_void_p)]),
+    "havac_host_create_deferred": (C.c_int, [C.c_uint32, C.c_float, C.POINTER(C.c_void_p)]),
     "havac_host_create_multi": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint32, C.c_float, C.POINTER(C.c_void_p)]),
     "havac_host_destroy": (None, [_vp]),
     "havac_host_load_sequence": (C.c_int, [_vp, C.c_char_p]),
@@ -48,6 +49,7 @@ HOST_SIGNATURES = {
                                                _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "havac_host_project_hmm": (C.c_int, [C.c_char_p, C.c_float, _vp, C.c_uint64, C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint32), _vp, C.c_uint32]),
+    "havac_host_read_hmm_emissions": (C.c_int, [C.c_char_p, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "havac_host_scaling_factor": (C.c_float, [C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_float]),
     "havac_host_project_score": (C.c_float, [C.c_float, C.c_float]),
     "havac_host_project_model": (C.c_int, [C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_float, _vp, _vp]),
@@ -96,11 +98,15 @@ def _hits_from_arrays(sp, si, pp, pi):
 
 
 class Havac:
-    def __init__(self, deviceIndex: int = 0, requiredPValue: float = 0.02, xclbinSrc: str = "", deviceIndices=None):
-        """deviceIndices (an addition): several GPUs behind one object, one column shard each."""
+    def __init__(self, deviceIndex: int = 0, requiredPValue: float = 0.02, xclbinSrc: str = "", deviceIndices=None,
+                 deferredStart: bool = False):
+        """deviceIndices (an addition): several GPUs behind one object, one column shard each.
+        deferredStart (an addition): Havac::DeferredStart -- the device layer starts under the caller's next calls."""
         self._L = load_host()
         h = C.c_void_p()
-        if deviceIndices is not None:
+        if deferredStart:
+            rc = self._L.havac_host_create_deferred(deviceIndex, requiredPValue, C.byref(h))
+        elif deviceIndices is not None:
             arr = (C.c_uint32 * len(deviceIndices))(*deviceIndices)
             rc = self._L.havac_host_create_multi(arr, len(deviceIndices), requiredPValue, C.byref(h))
         else:
@@ -278,6 +284,20 @@ def project_hmm(path: str, p_value: float = 0.02):
     if rc != 0:
         raise_for(rc, f"could not read {path}")
     return out.reshape(-1, 4), lens
+
+
+def read_hmm_emissions(path: str):
+    """P7HmmReader alone -> (float32 [positions, 4] match-emission file values of all models back to back, model count)."""
+    L = load_host()
+    n, nm = C.c_uint64(0), C.c_uint32(0)
+    rc = L.havac_host_read_hmm_emissions(os.fsencode(path), None, 0, C.byref(n), C.byref(nm))
+    if rc != 0:
+        raise_for(rc, f"could not read {path}")
+    out = np.empty(n.value, np.float32)
+    rc = L.havac_host_read_hmm_emissions(os.fsencode(path), out.ctypes.data, out.size, C.byref(n), C.byref(nm))
+    if rc != 0:
+        raise_for(rc, f"could not read {path}")
+    return out.reshape(-1, 4), nm.value
 
 
 def scaling_factor(mu, lam, max_length, model_length, p_value) -> float:

@@ -21,6 +21,9 @@ typedef struct havac_host havac_host;
 
 /* Havac::Havac(deviceIndex, requiredPValue, xclbinSrc)  host/Havac.cpp:20-31 */
 int havac_host_create(uint32_t device_index, float required_p_value, havac_host **out);
+/* Havac(Havac::DeferredStart, ...) (an addition): returns at once, the device layer starts on a helper thread under the
+ * caller's next calls; a device that cannot be opened is reported by the first call that needs it (HAVAC_E_RUNTIME). */
+int havac_host_create_deferred(uint32_t device_index, float required_p_value, havac_host **out);
 /* Havac over several GPUs of one node, one column shard each (an addition; include/havac_dev.h) */
 int havac_host_create_multi(const uint32_t *device_indices, uint32_t ndevices, float required_p_value, havac_host **out);
 void havac_host_destroy(havac_host *h);
@@ -59,6 +62,10 @@ int havac_host_pack_fasta(const char *fasta_path, int64_t seed, uint8_t *out, ui
 /* P7HmmReader + PhmmPreprocessor: file -> concatenated int8 [row][A,C,G,T]. */
 int havac_host_project_hmm(const char *hmm_path, float p_value, int8_t *out, uint64_t cap, uint64_t *nbytes,
                            uint32_t *nmodels, uint32_t *model_lengths, uint32_t lengths_cap);
+
+/* P7HmmReader alone: the match-emission file values (-ln p; +inf for '*') of every model of the file, back to back,
+ * [position][A,C,G,T].  Writes at most `cap` floats; *nvalues = the full count.  (Checking aid for the reader.) */
+int havac_host_read_hmm_emissions(const char *hmm_path, float *out, uint64_t cap, uint64_t *nvalues, uint32_t *nmodels);
 
 /* p7HmmProjectForThreshold256 on explicit parameters (PhmmReprojection.cpp:109-145): `emissions` = model_length x 4
  * match-emission file values (-ln p, +inf for '*'), `out` = model_length x 4 int8. */

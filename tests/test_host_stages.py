@@ -143,6 +143,71 @@ def test_hmm_reader_and_projection_of_a_collection(tmp_path):
     assert got[50 + 3, 2] == -128
 
 
+def exactly_rounded_float32(text):
+    """the binary32 nearest the decimal `text` (ties to even), computed with exact rational arithmetic"""
+    from fractions import Fraction
+    x = Fraction(text)
+    c = np.float32(float(x))
+    best, best_err = None, None
+    for cand in (np.nextafter(c, np.float32(-np.inf)), c, np.nextafter(c, np.float32(np.inf))):
+        err = abs(Fraction(float(cand)) - x)
+        even = (int(np.array(cand, np.float32).view(np.uint32)) & 1) == 0
+        if best is None or err < best_err or (err == best_err and even):
+            best, best_err = cand, err
+    return np.float32(best)
+
+
+def test_hmm_reader_converts_decimals_exactly_and_in_parallel(tmp_path):
+    """The reader turns plain decimals of up to seven significant digits into floats with one float division (digits /
+    10^k) and sends everything else to strtof; both must give the correctly rounded binary32 -- the int8 projection
+    rounds at .5 boundaries and a last-bit difference in an emission can flip a score.  Checked against exact rational
+    arithmetic on thousands of values in every spelling a file can hold, in a file big enough (> 256 KB, hundreds of
+    models) for the records to be parsed on several threads, and the model order must survive that."""
+    rng = np.random.default_rng(123)
+    texts = []
+    for _ in range(40000):
+        kind = rng.integers(0, 8)
+        if kind == 0:
+            t = f"{rng.uniform(0, 9):.5f}"                                   # what hmmbuild writes
+        elif kind == 1:
+            t = f"{rng.uniform(0, 0.001):.5f}"                               # tiny: many leading zeros
+        elif kind == 2:
+            t = f"{rng.uniform(0, 40):.{int(rng.integers(0, 7))}f}"          # other precisions, integers ("17")
+        elif kind == 3:
+            t = f"{rng.uniform(0, 20):.9f}"                                  # more than seven digits: strtof
+        elif kind == 4:
+            t = f"{rng.uniform(0, 20):.4e}"                                  # exponent form: strtof
+        elif kind == 5:
+            t = "0." + "".join(rng.choice(list("0123456789"), size=int(rng.integers(1, 11))))
+        elif kind == 6:
+            t = str(int(rng.integers(0, 10_000_000)))                        # up to seven digits, no point
+        else:
+            t = f"{rng.integers(0, 99)}."                                    # trailing point
+        texts.append(t)
+    L = 50
+    nmodels = len(texts) // (4 * L)
+    values = np.array(texts[: nmodels * 4 * L]).reshape(nmodels, L, 4)
+    lines = []
+    for m in range(nmodels):
+        lines += ["HMMER3/f [3.1b2 | February 2015]", f"NAME  m{m}", f"LENG  {L}", "MAXL  300", "ALPH  DNA",
+                  "STATS LOCAL MSV       -9.1000  0.71000", "HMM          A        C        G        T   ",
+                  "            m->m     m->i     m->d     i->m     i->i     d->m     d->d",
+                  "  COMPO   1.38629  1.38629  1.38629  1.38629", "          1.38629  1.38629  1.38629  1.38629",
+                  "          0.01005  5.29832  5.29832  0.61958  0.77255  0.00000        *"]
+        for k in range(L):
+            lines += [f"{k + 1:7d}   " + "  ".join(values[m, k]) + f" {k + 1:6d} a - - -",
+                      "          1.38629  1.38629  1.38629  1.38629",
+                      "          0.01005  5.29832  5.29832  0.61958  0.77255  0.48576  0.95510"]
+        lines.append("//")
+    path = tmp_path / "decimals.hmm"
+    path.write_text("\n".join(lines) + "\n")
+    assert path.stat().st_size > (1 << 18)                                   # big enough for the threaded path
+    got, count = havac.read_hmm_emissions(str(path))
+    assert count == nmodels and got.shape == (nmodels * L, 4)
+    want = np.array([exactly_rounded_float32(t) for t in values.reshape(-1)], np.float32).reshape(-1, 4)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))         # bit for bit, model order kept
+
+
 def test_hmm_format_errors(tmp_path):
     bad = tmp_path / "bad.hmm"
     bad.write_text("this is not a profile\n")
@@ -157,6 +222,28 @@ def test_hmm_format_errors(tmp_path):
     trunc.write_text("\n".join(text[:-8]) + "\n")            # cut inside the body, no "//"
     with pytest.raises(RuntimeError):
         havac.project_hmm(str(trunc))
+    good = "\n".join(text) + "\n"
+    first_node = next(i for i, l in enumerate(text) if l.split()[:1] == ["1"] and len(l.split()) > 5)
+    def with_line(i, new_line):
+        return "\n".join(text[:i] + [new_line] + text[i + 1:]) + "\n"
+    tokens = text[first_node].split()
+    cases = {
+        "garbage_between": good + "stray line\n" + good,                      # something between two records
+        "garbage_before": "stray\n" + good,
+        "bad_number": with_line(first_node, " ".join([tokens[0], "1.2x3"] + tokens[2:])),   # a match emission that is not a number
+        "too_few_scores": with_line(first_node, " ".join(tokens[:3])),
+        "wrong_node_number": with_line(first_node + 3, text[first_node + 3].replace("2", "7", 1)),
+        "leng_too_big": good.replace("LENG  10", "LENG  4000000000"),
+        "no_leng": good.replace("LENG  10\n", ""),
+    }
+    for name, broken in cases.items():
+        f = tmp_path / (name + ".hmm")
+        f.write_text(broken)
+        with pytest.raises(RuntimeError):
+            havac.project_hmm(str(f))
+    ok = tmp_path / "blank_lines.hmm"
+    ok.write_text("\n\n" + good + "\n   \n" + good.replace("\n", "\r\n"))            # blank lines around records, CRLF
+    assert havac.project_hmm(str(ok))[1].tolist() == [10, 10]
 
 
 # ---------------------------------------------------------------- resolver

@@ -50,7 +50,7 @@ def test_host_stages_under_asan_ubsan(tmp_path):
                   "          " + "  ".join(["2.99573"] * 20),
                   "          0.01005  5.29832  5.29832  0.61958  0.77255  0.48576  0.95510"]
     (tmp_path / "amino.hmm").write_text("\n".join(amino + ["//"]) + "\n")
-    exe = build(["g++", "-std=c++17", "-ffp-contract=off", *FLAGS, "-I" + HOST, os.path.join(ROOT, "tests", "native", "host_sanitize.cpp")] +
+    exe = build(["g++", "-std=c++17", "-pthread", "-ffp-contract=off", *FLAGS, "-I" + HOST, os.path.join(ROOT, "tests", "native", "host_sanitize.cpp")] +
                 [os.path.join(HOST, f) for f in ("FastaVector.cpp", "p7HmmReader.cpp", "SequencePreprocessor.cpp",
                                                  "PhmmPreprocessor.cpp", "PhmmReprojection.cpp")], str(tmp_path / "host_san"))
     names = ["a.fa", "b.fa", "c.fa", "d.fa", "missing.fa", "m.hmm", "cut.hmm", "cut2.hmm", "missing.hmm", "amino.hmm"]

@@ -1,10 +1,10 @@
-"""Kernel time of tall-model workloads with and without row blocks (HAVAC_ROWS_PER_BLOCK).  python tools/split_probe.py"""
+"""Kernel time of tall-model workloads with and without row blocks (bench.py --tuning).  python tools/split_probe.py"""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for rpb in ("0", "4096", "8192", "16384"):
-    env = dict(os.environ, HAVAC_ROWS_PER_BLOCK=rpb)
+    env = dict(os.environ)
     for w in ("c5", "c3"):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--no-pmc", "--no-cpu-baseline", "--steps", "4", "--warmup", "1"],
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--no-pmc", "--no-cpu-baseline", "--steps", "4", "--warmup", "1", f"--tuning={rpb},-1,-1,-1"],
                            capture_output=True, text=True, env=env)
         import json
         try:
