@@ -27,8 +27,11 @@ Workloads (BASELINE.json configs):
                 database is cut into N runs of whole segments, one per rank
   c5            one pHMM of L = 20000 rows x 100 Mbp per GPU; weak-scaled
 The database is cut into N runs of whole 12288-column segments, one per rank (havac_amd/dist.py; a rank recomputes a
-left halo of rows-1 columns); every rank holds the whole packed sequence in its own HBM (C4: 250 MB), so there is no
-data-path collective.
+left halo of rows-1 columns); a rank keeps in its HBM only the columns its shard reads (havac_ssv_shard_window: its own,
+the halo, a few thousand for the tiling -- C4: 31 MB of the 250 MB), and there is no data-path collective.
+For N > 1 rank 0 checks the gathered list before it prints (`distributed.parity`): device order, no duplicates, the
+ranks' counts add up, every rank's records lie inside its columns, and the records around two shard boundaries equal
+the CPU checker's.
 
 GCUPS = defined DP cells (columns x rows; padding outside the matrix and halo recomputation are not
 counted) / wall time of the K timed steps, max over ranks.
@@ -65,9 +68,10 @@ FPGA_GCUPS = 1739.0                    # reference README.md:4 (Alveo U50), BASE
 # name -> (rows or None for the 1000-model collection, real symbols per unit, scaling); a unit is one GPU's share
 # for weak scaling and the whole database for strong scaling
 WORKLOADS = {
-    # (warm-up: the GPU needs ~10 launches of 2 ms to reach its clock under this load -- the kernel's duration falls from 2.11
-    # to 1.83 ms over the first ten launches of a run, profiles/r02b_kernel_stats_c2.csv -- so the default warm-up is 20 passes)
-    "c2": dict(rows=1024, real=100_000_000, scaling="weak", steps=50, warmup=20,
+    # (the GPU needs ~10 launches of 2 ms to reach its clock under this load -- the kernel's duration falls from 2.11 to 1.83 ms
+    # over the first ten launches of a run, profiles/r02b_kernel_stats_c2.csv; bench.py runs its own clock warm-up in front
+    # of the --warmup passes and reports how many passes that took: `clock_warmup_passes`)
+    "c2": dict(rows=1024, real=100_000_000, scaling="weak", steps=50, warmup=5,
                label="C2: 1 pHMM L=1024 x 100 Mbp (100,012,032 columns padded to 12288) per GPU"),
     "c3": dict(rows=None, real=10_000_000, scaling="weak", steps=10, warmup=2,
                label="C3: 1000-model collection (L 50-2000, 503,329 rows concatenated) x 10 Mbp (10,002,432 columns) per GPU"),
@@ -245,6 +249,16 @@ def cpu_baseline(packed: np.ndarray, model: np.ndarray, gpu_hits, cores: int, wh
                   f"{len(blocks)} threads each a column block with a {R - 1}-column left halo)",
         "hits_match_gpu": match, "hits_in_sample": int(cpu_hits.size),
     }
+    # SURVEY.md 8d's other CPU figure: the reference-shaped loop nest (test/softSsv/SoftSsv.cpp:31-62) on ONE core
+    one_cols = int(min(sample_cols, max(40_000, 1.5e9 / R))) // 4 * 4
+    t1 = time.perf_counter()
+    one_hits = O.ssv_reference(sym[:one_cols], sub) if use_ref else O.ssv(sym[:one_cols], sub)
+    dt_one = time.perf_counter() - t1
+    out["single_thread"] = {
+        "value": round(one_cols * R / dt_one / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": "reference" if use_ref else "port",
+        "sample": f"first {one_cols} columns x first {R} rows ({one_cols * R:.3g} cells, {dt_one:.1f} s wall), one thread, the "
+                  "reference's loop nest (rows outer, columns inner, one u8 row buffer)",
+        "hits_match_gpu": bool(np.array_equal(O.device_order(one_hits), O.device_order(gpu_hits(0, one_cols, R))))}
     ncols = packed.size * 4
     if ncols * nrows <= whole_list_limit_cells:
         # second CPU figure: our AVX2 restatement (oracle.ssv_fast) over the WHOLE workload, which also lets the bench
@@ -278,6 +292,73 @@ def cpu_baseline(packed: np.ndarray, model: np.ndarray, gpu_hits, cores: int, wh
     return out
 
 
+class OrderedHits:
+    """The ordered record list of a pass (a torch int64 tensor on the device, device order = segment-major) with the
+    lookups the checks need."""
+
+    def __init__(self, merged, nrows):
+        self.merged, self.nrows, self.n = merged, nrows, int(merged.numel())
+
+    def first_of_segment(self, seg):
+        """index of the first record of segment >= seg"""
+        lo_i, hi_i = 0, self.n
+        while lo_i < hi_i:
+            mid = (lo_i + hi_i) // 2
+            if ((int(self.merged[mid].item()) >> 14) & 0x3FFFFFF) < seg:
+                lo_i = mid + 1
+            else:
+                hi_i = mid
+        return lo_i
+
+    def window(self, col_lo, col_hi, row_hi):
+        """the records with col_lo <= column < col_hi and row < row_hi: the segments that hold those columns are one
+        contiguous slice of the ordered list; the rest is filtered on the device"""
+        part = self.merged[self.first_of_segment(col_lo // SEGMENT): self.first_of_segment((col_hi + SEGMENT - 1) // SEGMENT)]
+        cols = ((part >> 14) & 0x3FFFFFF) * SEGMENT + (part & 0x3FFF)
+        keep = (cols >= col_lo) & (cols < col_hi)
+        if row_hi < self.nrows:
+            keep &= ((part >> 40) & 0xFFFFFF) < row_hi
+        return part[keep].cpu().numpy().view(np.uint64)
+
+
+def distributed_parity(hits: OrderedHits, counts, spans, packed, model, cores, stretch=200_000):
+    """What rank 0 checks on the gathered list of an N > 1 run before it prints: the list is in the reference's device
+    order without duplicates; the ranks' counts add up to it; every rank's records lie inside that rank's columns; and
+    around (up to) two shard boundaries -- `stretch` columns on either side: the cut side of the left rank, the halo side
+    of the right one -- the records equal the CPU checker's, every one of them."""
+    from oracle import pyoracle as O
+    merged, n = hits.merged, hits.n
+    out = {"records": n, "counts_add_up": int(sum(counts)) == n}
+    seg = (merged >> 14) & 0x3FFFFFF
+    key = (seg << 38) | (((merged >> 40) & 0xFFFFFF) << 14) | (merged & 0x3FFF)      # segment | row | column: the emission order
+    out["device_order_no_duplicates"] = bool((key[1:] > key[:-1]).all().item()) if n > 1 else True
+    inside, at = True, 0
+    for (lo, hi), c in zip(spans, counts):
+        if c:
+            mine = seg[at: at + c]
+            inside = inside and int(mine.min().item()) >= lo // SEGMENT and int(mine.max().item()) < hi // SEGMENT
+        at += c
+    out["ranks_inside_their_columns"] = bool(inside)
+    nrows, ncols = model.shape[0], packed.size * 4
+    boundaries = sorted({spans[0][1], spans[-1][0]}) if len(spans) > 1 else []
+    checked = []
+    for cut in boundaries:
+        a, b = max(0, cut - stretch), min(ncols, cut + stretch)
+        start = max(0, a - (nrows - 1)) // 4 * 4
+        sym = synth.unpack_2bit(packed[start // 4: (b + 3) // 4])[: b - start]
+        mine = hits.window(a, b, nrows)
+        want = O.ssv_fast(sym, model, nthreads=cores, cap=mine.size + (1 << 22))
+        rows_w, cols_w = O.unpack_hits(want)
+        keep = cols_w + np.uint64(start) >= np.uint64(a)
+        want = O.device_order(O.pack_hits(rows_w[keep], cols_w[keep] + np.uint64(start)))
+        checked.append({"boundary_column": int(cut), "columns": [int(a), int(b)], "records": int(want.size),
+                        "equals_cpu_checker": bool(np.array_equal(want, mine))})
+    out["boundary_stretches"] = checked
+    out["ok"] = bool(out["counts_add_up"] and out["device_order_no_duplicates"] and out["ranks_inside_their_columns"] and
+                     all(c["equals_cpu_checker"] for c in checked))
+    return out
+
+
 def launch_workers(args, argv):
     """python bench.py --gpus N without a launcher: start N ranks as a child process (nothing in this process has
     touched a GPU), pass their output through, exit with their code."""
@@ -305,6 +386,7 @@ def main():
     ap.add_argument("--tuning", default="", help="experiments: rows_per_block,tiles_per_item,block_tails,ordering for "
                     "havac_ssv_set_tuning (-1 = the library's own rule), e.g. --tuning=-1,-1,-1,0 orders with the radix sort")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true", help="N > 1: skip rank 0's check of the gathered list (distributed.parity)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--pmc-timeout", type=int, default=240)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -358,16 +440,23 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    d_seq = torch.from_numpy(packed).to(device)
+    from havac_amd.ssv import shard_window
+    # a rank holds only the columns its shard reads (N > 1); the host copy stays whole for the checks behind the timed region
+    win_first, win_end = shard_window(ncols, nrows, rank, world) if world > 1 else (0, ncols)
+    d_seq = torch.from_numpy(packed[win_first // 4: win_end // 4]).to(device)
     d_phmm = torch.from_numpy(model.reshape(-1)).to(device)
 
     my_cells = shard_cells(ncols, nrows, rank, world)
     total_cells = ncols * nrows
     # records per cell: 1.0e-5 on C2, 0.9e-5 on the collection
     hit_capacity = max(1 << 20, int(my_cells * (4e-5 if my_cells <= 1e13 else 1.2e-5)))
-    depth = args.pipeline_depth if args.pipeline_depth > 0 else (3 if my_cells <= 1e12 else 1)
+    # passes in flight: 3 for short passes; for long ones 2 when there is a gather to hide behind the next kernel (N > 1:
+    # C4 moves 36 GB to rank 0 per pass), else 1
+    depth = args.pipeline_depth if args.pipeline_depth > 0 else (3 if my_cells <= 1e12 else (2 if world > 1 else 1))
     tuning = [int(v) for v in args.tuning.split(",")] if args.tuning else None
     engine = ShardedSsv(hit_capacity, device, depth=depth, gather_when_alone=use_dist, tuning=tuning)
+    if world > 1:
+        engine.set_sequence_window(win_first, win_end - win_first)
 
     def fence():
         if use_dist:
@@ -390,7 +479,24 @@ def main():
     # set-up, not warm-up: one pass through every slot so that each context has its sort buffers before anything is
     # timed (a slot first used inside the timed region would pay a hipMalloc there when --warmup < --pipeline-depth)
     run_steps(engine, depth)
-    run_steps(engine, max(0, args.warmup - depth))
+    # Clock warm-up, independent of --warmup: under this load the GPU reaches its clock only after ~10 launches of 2 ms (the
+    # kernel's duration falls from 2.11 to 1.83 ms over the first ten launches of a run).  Untimed passes until the kernel's
+    # event time has stopped falling -- three passes in a row within 0.5 % of the best seen -- at most 30 passes or 3 s.
+    clock_passes, best_ms, steady, t_clock = 0, None, 0, time.perf_counter()
+    while True:
+        _, t = run_steps(engine, 1)
+        clock_passes += 1
+        k_ms = t[-1][0]
+        steady = steady + 1 if (best_ms is not None and k_ms <= best_ms * 1.005) else 0
+        best_ms = k_ms if best_ms is None else min(best_ms, k_ms)
+        done = steady >= 3 or clock_passes >= 30 or time.perf_counter() - t_clock > 3.0
+        if use_dist:      # a pass holds a collective: every rank goes on until all are done
+            flag = torch.tensor([1 if done else 0], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            done = bool(flag.item())
+        if done:
+            break
+    run_steps(engine, args.warmup)
     engine.gather_times()
     engine.gather_ms = []
     fence()
@@ -404,6 +510,8 @@ def main():
         if rank == 0 and merged is not None:
             merged = merged.clone()
         serial = ShardedSsv(hit_capacity, device, depth=1, gather_when_alone=use_dist, tuning=tuning)
+        if world > 1:
+            serial.set_sequence_window(win_first, win_end - win_first)
         run_steps(serial, 2)
         fence()
         t1 = time.perf_counter()
@@ -440,6 +548,7 @@ def main():
         out = {
             "metric": "GCUPS (billion SSV cells/s); hit-list bit-exact vs softSsv",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "clock_warmup_passes": clock_passes,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": w["scaling"],
             "vs_baseline": round(gcups / FPGA_GCUPS, 3), "dtype": "i16",
             "data": "synthetic",
@@ -482,31 +591,13 @@ def main():
                 "gather_ms_rank0": round(float(np.mean(gather_ms)), 4) if gather_ms else None,
                 "per_rank": per_rank,
             }
+        cores = min(16, len(os.sched_getaffinity(0)))   # a 1-GPU box's CPU share
+        ordered = OrderedHits(merged, nrows)
+        if use_dist and not args.no_parity_check:
+            spans = [tuple(r["columns"]) for r in per_rank]
+            out["distributed"]["parity"] = distributed_parity(ordered, [r["records"] for r in per_rank], spans, packed, model, cores)
         if world == 1 and not args.no_cpu_baseline:
-            cores = min(16, len(os.sched_getaffinity(0)))   # a 1-GPU box's CPU share
-
-            def first_of_segment(seg):
-                """index of the first record of segment >= seg: the list is in device order, segment-major"""
-                lo_i, hi_i = 0, nhits
-                while lo_i < hi_i:
-                    mid = (lo_i + hi_i) // 2
-                    if ((int(merged[mid].item()) >> 14) & 0x3FFFFFF) < seg:
-                        lo_i = mid + 1
-                    else:
-                        hi_i = mid
-                return lo_i
-
-            def gpu_hits(col_lo, col_hi, row_hi):
-                """the GPU's records with col_lo <= column < col_hi and row < row_hi: the segments that hold those
-                columns are one contiguous slice of the ordered list; the rest is filtered on the device"""
-                part = merged[first_of_segment(col_lo // SEGMENT): first_of_segment((col_hi + SEGMENT - 1) // SEGMENT)]
-                cols = ((part >> 14) & 0x3FFFFFF) * SEGMENT + (part & 0x3FFF)
-                keep = (cols >= col_lo) & (cols < col_hi)
-                if row_hi < nrows:
-                    keep &= ((part >> 40) & 0xFFFFFF) < row_hi
-                return part[keep].cpu().numpy().view(np.uint64)
-
-            out["cpu_baseline"] = cpu_baseline(packed, model, gpu_hits, cores)
+            out["cpu_baseline"] = cpu_baseline(packed, model, ordered.window, cores)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -48,6 +48,8 @@ SIGNATURES = {
     "havac_ssv_ctx_destroy": (None, [_vp]),
     "havac_ssv_enqueue": (C.c_int, [_vp, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "havac_ssv_shard_window": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "havac_ssv_set_sequence_window": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
     "havac_ssv_set_separator_mask": (C.c_int, [_vp, C.c_void_p]),
     "havac_ssv_set_order_stream": (C.c_int, [_vp, C.c_void_p]),
     "havac_ssv_set_cell_trace": (C.c_int, [_vp, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]),

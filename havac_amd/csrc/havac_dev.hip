@@ -81,6 +81,18 @@ void shard_tiles(const Tiling& t, uint32_t nrows, uint64_t col_begin, uint64_t c
     if (*te > t.ntiles) *te = t.ntiles;
 }
 
+// The columns the launch of shard [col_begin, col_end) READS: its own, the left halo of the diagonals that reach it
+// (rows - 1 columns), and what the tiling adds at both ends -- a tile starts up to 2047 diagonals left of the first one
+// needed, and a wave fetches the symbols of the chunk after the one it works on (ssv_diag_body: fetch_symbols).  Whole
+// segments, clipped to the database.
+void shard_window(uint64_t nsymbols, uint32_t nrows, uint64_t col_begin, uint64_t col_end, uint64_t* first, uint64_t* end) {
+    const uint64_t reach = (uint64_t)round_up(nrows, kChunkRows) + 2 * kTileDiags;
+    const uint64_t lo = col_begin > reach ? col_begin - reach : 0;
+    const uint64_t hi = std::min<uint64_t>(nsymbols, col_end + 2 * kTileDiags);
+    *first = lo / HAVAC_SEGMENT_COLUMNS * HAVAC_SEGMENT_COLUMNS;
+    *end = std::min<uint64_t>(nsymbols, (hi + HAVAC_SEGMENT_COLUMNS - 1) / HAVAC_SEGMENT_COLUMNS * HAVAC_SEGMENT_COLUMNS);
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -113,6 +125,7 @@ struct havac_ssv_ctx {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pass start, kernel start, kernel end, records ordered, count on the host
     CellRecord* trace_cells = nullptr; uint32_t trace_row0 = 0, trace_rows = 0, trace_cols = 0; uint64_t trace_col0 = 0;   // per-cell trace window (debugging)
     hipStream_t order_stream = nullptr;        // optional: where finish() orders the records (default: the enqueue's stream)
+    uint64_t window_first = 0, window_columns = 0;   // the caller's sequence buffer holds only these columns (0, 0: all of them)
     // experiment knobs (havac_ssv_set_tuning): -1 = the library decides
     int tune_rows_per_block = -1, tune_tiles_per_item = -1, tune_block_tails = -1;
     // the pass enqueue() started and finish() completes
@@ -214,6 +227,28 @@ extern "C" int havac_ssv_set_order_stream(havac_ssv_ctx* c, void* hip_stream) {
     return HAVAC_OK;
 }
 
+extern "C" int havac_ssv_shard_window(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index, uint32_t shard_count,
+                                      uint64_t* first_column, uint64_t* end_column) {
+    if (!first_column || !end_column || shard_count == 0 || shard_index >= shard_count || nsymbols == 0 || nrows == 0 ||
+        nsymbols % HAVAC_SEGMENT_COLUMNS != 0)
+        return HAVAC_E_ARGUMENT;
+    uint64_t b, e;
+    shard_columns(nsymbols, shard_index, shard_count, &b, &e);
+    shard_window(nsymbols, nrows, b, e, first_column, end_column);
+    return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_set_sequence_window(havac_ssv_ctx* c, uint64_t first_column, uint64_t ncolumns) {
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (c->pending) { c->err = "a pass is in flight: set the sequence window between passes"; return HAVAC_E_LOGIC; }
+    if (first_column % HAVAC_SEGMENT_COLUMNS != 0 || ncolumns % HAVAC_SEGMENT_COLUMNS != 0) {
+        c->err = "a sequence window is a run of whole 12288-column segments";
+        return HAVAC_E_ARGUMENT;
+    }
+    c->window_first = first_column; c->window_columns = ncolumns;
+    return HAVAC_OK;
+}
+
 extern "C" int havac_ssv_set_tuning(havac_ssv_ctx* c, int rows_per_block, int tiles_per_item, int block_tails, int ordering) {
     if (!c) return HAVAC_E_ARGUMENT;
     if (c->pending) { c->err = "a pass is in flight: change the tuning between passes"; return HAVAC_E_LOGIC; }
@@ -292,6 +327,19 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     shard_columns(nsymbols, shard_index, shard_count, &col_begin, &col_end);
     uint32_t tb, te;
     shard_tiles(t, nrows, col_begin, col_end, &tb, &te);
+    if (c->window_columns) {
+        // the caller's buffer holds columns [window_first, window_first + window_columns) only: it must cover what this
+        // shard's launch reads; the kernel is handed the address column 0 would have
+        uint64_t need_first, need_end;
+        shard_window(nsymbols, nrows, col_begin, col_end, &need_first, &need_end);
+        if (c->window_first > need_first || c->window_first + c->window_columns < need_end) {
+            c->err = "the sequence window [" + std::to_string(c->window_first) + ", " + std::to_string(c->window_first + c->window_columns) +
+                     ") does not cover the columns this shard reads [" + std::to_string(need_first) + ", " + std::to_string(need_end) + ")";
+            return HAVAC_E_ARGUMENT;
+        }
+        d_sequence -= c->window_first / 4;
+    }
+    const uint16_t* const pair_mask = c->pair_mask ? c->pair_mask - (c->window_columns ? c->window_first / 32 : 0) : nullptr;
 
     HIP_TRY(c->err, hipEventRecord(c->ev[0], stream));
     // one launch: the padded copy of the model, the chunk flags, the cleared hit counter.  (Separator pairs score -128 twice
@@ -362,7 +410,7 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         SsvRare& R = L;
         R.hits = d_hits; R.hit_count = c->d_count; R.hit_capacity = hit_capacity;
         R.col_begin = (int64_t)col_begin; R.col_span = col_end - col_begin;
-        R.abort_flag = d_abort_flag; R.pair_mask = c->pair_mask; R.tickets = c->tickets; R.block_flags = c->block_flags; R.block_state = c->block_state;
+        R.abort_flag = d_abort_flag; R.pair_mask = pair_mask; R.tickets = c->tickets; R.block_flags = c->block_flags; R.block_state = c->block_state;
         R.fault = c->tickets + kTicketCounters * kTicketStride; R.row_bits = row_bits;
         // block tails: a side buffer of kTailSlots keys per block, where blocks are short-lived -- items of up to 512 rows: a
         // block of C2 (1024 rows) lives 200 us and loses nothing to the one atomic at its end, while its tail would cross
@@ -616,6 +664,7 @@ struct DevicePart {
     uint8_t* d_seq = nullptr; uint64_t seq_alloc = 0;
     int8_t* d_phmm = nullptr; uint64_t phmm_alloc = 0;
     uint8_t* d_mask = nullptr; uint64_t mask_alloc = 0;   // separator bitmap, optional
+    uint64_t win_first = 0, win_columns = 0;              // d_seq / d_mask hold these columns only (0, 0: all); see upload_columns
     uint64_t* d_hits = nullptr;
     uint32_t* d_abort = nullptr;        // device word the kernel polls (cache-bypassing loads)
     hipStream_t abort_stream = nullptr; // abort() writes the word from here while the kernel runs
@@ -738,6 +787,45 @@ static int upload(havac_dev* d, T* DevicePart::*buf, uint64_t DevicePart::*alloc
     return HAVAC_OK;
 }
 
+// The same for a per-column buffer (the packed sequence: 4 columns per byte; the separator bitmap: 16) when the handle
+// drives several GPUs: GPU i receives only the columns shard i can ever read -- its own and a left halo for the tallest
+// model the record format allows (2^24 - 1 rows: 4 MB of packed sequence), since the model may be written later.  The
+// reference has one device per object and a 4 GiB limit per object; eight GPUs each holding a full copy would be
+// 8 x 4 GiB at that limit.
+static const uint32_t kTallestModel = (1u << 24) - 1;
+static void part_window(const havac_dev* d, uint64_t ncolumns, uint32_t part, uint64_t* first, uint64_t* columns) {
+    const uint32_t nparts = (uint32_t)d->parts.size();
+    if (nparts == 1 || ncolumns / HAVAC_SEGMENT_COLUMNS < nparts) { *first = 0; *columns = 0; return; }
+    uint64_t b, e, wf, we;
+    shard_columns(ncolumns, part, nparts, &b, &e);
+    shard_window(ncolumns, kTallestModel, b, e, &wf, &we);
+    *first = wf; *columns = we - wf;
+}
+template <typename T>
+static int upload_columns(havac_dev* d, T* DevicePart::*buf, uint64_t DevicePart::*alloc, const uint8_t* src, uint64_t ncolumns,
+                          uint32_t columns_per_byte) {
+    for (uint32_t i = 0; i < d->parts.size(); i++) {
+        DevicePart& p = d->parts[i];
+        HIP_TRY(d->err, hipSetDevice(p.device));
+        part_window(d, ncolumns, i, &p.win_first, &p.win_columns);
+        const uint64_t first = p.win_first, columns = p.win_columns ? p.win_columns : ncolumns;
+        const uint64_t nbytes = columns / columns_per_byte;
+        if (p.*alloc < nbytes) {
+            if (p.*buf) (void)hipFree(p.*buf);
+            p.*buf = nullptr; p.*alloc = 0;
+            HIP_TRY(d->err, hipMalloc(&(p.*buf), nbytes));
+            p.*alloc = nbytes;
+        }
+        HIP_TRY(d->err, hipMemcpyAsync(p.*buf, src + first / columns_per_byte, nbytes, hipMemcpyHostToDevice, p.stream));
+    }
+    for (DevicePart& p : d->parts) {
+        HIP_TRY(d->err, hipSetDevice(p.device));
+        HIP_TRY(d->err, hipStreamSynchronize(p.stream));
+    }
+    return HAVAC_OK;
+}
+static void whole_copies(havac_dev* d) { for (DevicePart& p : d->parts) p.win_first = p.win_columns = 0; }
+
 extern "C" int havac_dev_write_sequence(havac_dev* d, const uint8_t* packed, uint64_t nbytes) {
     if (!d || (!packed && nbytes)) return HAVAC_E_ARGUMENT;
     // host/HavacHwClient.cpp:81-97 (the reference computes the symbol count in 32 bits; we do not wrap)
@@ -754,7 +842,7 @@ extern "C" int havac_dev_write_sequence(havac_dev* d, const uint8_t* packed, uin
     d->seq_bytes = nbytes;
     d->mask_bytes = 0;                       // a new sequence has no separators until a mask is written for it
     if (nbytes == 0) return HAVAC_OK;
-    return upload(d, &DevicePart::d_seq, &DevicePart::seq_alloc, packed, nbytes);
+    return upload_columns(d, &DevicePart::d_seq, &DevicePart::seq_alloc, packed, nbytes * 4, 4);
 }
 
 // SURVEY.md section 8 row f4.  Text in, packed on the GPU.  Per GPU: two staging buffers of kCharChunk characters;
@@ -778,6 +866,7 @@ extern "C" int havac_dev_write_sequence_chars(havac_dev* d, const char* chars, u
         }
     d->seq_bytes = nbytes;
     d->mask_bytes = 0;
+    whole_copies(d);
     if (nbytes == 0) return HAVAC_OK;
     // page-locked source: the chunk copies then run at PCIe speed and truly asynchronously; if the pages cannot be
     // locked the copies still work, through the runtime's own staging
@@ -843,24 +932,35 @@ extern "C" int havac_dev_write_sequence_chars(havac_dev* d, const char* chars, u
     return rc;
 }
 
+// the first `nbytes` of a per-column buffer as the handle's GPUs hold it: every GPU contributes its own columns
+template <typename T>
+static int read_columns(havac_dev* d, T* DevicePart::*buf, uint8_t* out, uint64_t nbytes, uint64_t ncolumns, uint32_t columns_per_byte) {
+    const uint32_t nparts = (uint32_t)d->parts.size();
+    for (uint32_t i = 0; i < nparts; i++) {
+        DevicePart& p = d->parts[i];
+        uint64_t b = 0, e = ncolumns;
+        if (p.win_columns) shard_columns(ncolumns, i, nparts, &b, &e);
+        else if (i > 0) break;                                   // whole copies: the first GPU has everything
+        const uint64_t from = b / columns_per_byte, to = std::min(e / columns_per_byte, nbytes);
+        if (from >= to) continue;
+        HIP_TRY(d->err, hipSetDevice(p.device));
+        HIP_TRY(d->err, hipMemcpy(out + from, p.*buf + (from - p.win_first / columns_per_byte), to - from, hipMemcpyDeviceToHost));
+    }
+    return HAVAC_OK;
+}
+
 extern "C" int havac_dev_read_sequence(havac_dev* d, uint8_t* out, uint64_t nbytes) {
     if (!d || (!out && nbytes)) return HAVAC_E_ARGUMENT;
     if (nbytes > d->seq_bytes) { d->err = "the device holds fewer sequence bytes than requested"; return HAVAC_E_LENGTH; }
     if (nbytes == 0) return HAVAC_OK;
-    DevicePart& p = d->parts[0];
-    HIP_TRY(d->err, hipSetDevice(p.device));
-    HIP_TRY(d->err, hipMemcpy(out, p.d_seq, nbytes, hipMemcpyDeviceToHost));
-    return HAVAC_OK;
+    return read_columns(d, &DevicePart::d_seq, out, nbytes, d->seq_bytes * 4, 4);
 }
 
 extern "C" int havac_dev_read_separator_mask(havac_dev* d, uint8_t* out, uint64_t nbytes) {
     if (!d || (!out && nbytes)) return HAVAC_E_ARGUMENT;
     if (nbytes > d->mask_bytes) { d->err = "the device holds fewer separator-bitmap bytes than requested"; return HAVAC_E_LENGTH; }
     if (nbytes == 0) return HAVAC_OK;
-    DevicePart& p = d->parts[0];
-    HIP_TRY(d->err, hipSetDevice(p.device));
-    HIP_TRY(d->err, hipMemcpy(out, p.d_mask, nbytes, hipMemcpyDeviceToHost));
-    return HAVAC_OK;
+    return read_columns(d, &DevicePart::d_mask, out, nbytes, d->seq_bytes * 4, 16);
 }
 
 namespace {
@@ -899,6 +999,7 @@ extern "C" int havac_dev_write_sequence_records(havac_dev* d, const char* chars,
     }
     d->seq_bytes = nbytes;
     d->mask_bytes = 0;
+    whole_copies(d);
     if (nbytes == 0) return HAVAC_OK;
     const bool locked = nchars && hipHostRegister(const_cast<char*>(chars), nchars, hipHostRegisterDefault) == hipSuccess;
     if (!locked) (void)hipGetLastError();
@@ -947,6 +1048,11 @@ extern "C" int havac_dev_append_reverse_strand(havac_dev* d, const uint64_t* sta
     if (!d || (nrecords && (!starts || !residues))) return HAVAC_E_ARGUMENT;
     if (d->seq_bytes == 0) { d->err = "no sequence on the device to append a second strand to"; return HAVAC_E_LOGIC; }
     if (d->has_run && !d->finished) { d->err = "cannot change the sequence during a run"; return HAVAC_E_LOGIC; }
+    if (d->parts[0].win_columns) {
+        d->err = "the GPUs of this handle hold column windows of a host-packed sequence (havac_dev_write_sequence): append the "
+                 "second strand on the host, or send the text (havac_dev_write_sequence_chars / _records)";
+        return HAVAC_E_LOGIC;
+    }
     const uint64_t fbytes = d->seq_bytes, nf = fbytes * 4;
     if (2 * fbytes >= (4ull << 30)) {
         d->err = "compressed sequence size must be less than 4GiB. length requested: " + std::to_string(2 * fbytes) + " bytes.";
@@ -1007,7 +1113,9 @@ extern "C" int havac_dev_write_separator_mask(havac_dev* d, const uint8_t* pair_
         return HAVAC_E_LENGTH;
     }
     d->mask_bytes = nbytes;
-    return upload(d, &DevicePart::d_mask, &DevicePart::mask_alloc, pair_bitmap, nbytes);
+    // (the same columns per GPU as the sequence it belongs to)
+    if (d->parts[0].win_columns == 0) return upload(d, &DevicePart::d_mask, &DevicePart::mask_alloc, pair_bitmap, nbytes);
+    return upload_columns(d, &DevicePart::d_mask, &DevicePart::mask_alloc, pair_bitmap, d->seq_bytes * 4, 16);
 }
 
 extern "C" int havac_dev_write_phmm(havac_dev* d, const int8_t* scores, uint64_t nbytes) {
@@ -1046,6 +1154,7 @@ extern "C" int havac_dev_run_async(havac_dev* d) {
         HIP_TRY(d->err, hipSetDevice(p.device));
         HIP_TRY(d->err, hipMemsetAsync(p.d_abort, 0, sizeof(uint32_t), p.stream));
         havac_ssv_set_separator_mask(p.ctx, d->mask_bytes ? p.d_mask : nullptr);
+        havac_ssv_set_sequence_window(p.ctx, p.win_first, p.win_columns);
         int rc = havac_ssv_enqueue(p.ctx, p.d_seq, d->seq_bytes * 4, p.d_phmm, (uint32_t)(d->phmm_bytes / 4), i, nparts,
                                    p.d_hits, d->hit_capacity, p.d_abort, p.stream);
         if (rc) {

@@ -126,6 +126,12 @@ class ShardedSsv:
         self.gather_ms = []               # device time of each gather on this rank (filled by gather_times())
         self._timed = []
 
+    def set_sequence_window(self, first_column: int = 0, ncolumns: int = 0):
+        """the d_seq handed to submit() holds columns [first_column, first_column + ncolumns) of the database only
+        (havac_amd.ssv.shard_window tells a rank what it needs: its shard, the left halo, a little for the tiling)"""
+        for slot in self.slots:
+            slot.ctx.set_sequence_window(first_column, ncolumns)
+
     def submit(self, d_seq: torch.Tensor, nsymbols: int, d_phmm: torch.Tensor, nrows: int):
         if len(self.in_flight) == len(self.slots):
             raise RuntimeError("every slot is in flight: collect() first")

@@ -37,6 +37,10 @@ class SsvContext:
         self._check(self._L.havac_ssv_enqueue(self._h, d_sequence, nsymbols, d_phmm, nrows, shard_index, shard_count,
                                               d_hits, hit_capacity, d_abort_flag or None, stream or None))
 
+    def set_sequence_window(self, first_column: int = 0, ncolumns: int = 0):
+        """the d_sequence handed to the next passes holds columns [first_column, first_column + ncolumns) only (0, 0: all)"""
+        self._check(self._L.havac_ssv_set_sequence_window(self._h, first_column, ncolumns))
+
     def set_order_stream(self, stream: int = 0):
         """the HIP stream finish() orders the records on (0 = the stream of the enqueue)"""
         self._check(self._L.havac_ssv_set_order_stream(self._h, stream or None))
@@ -87,6 +91,16 @@ def shard_columns(nsymbols: int, shard_index: int, shard_count: int):
     """-> (col_begin, col_end): the whole 12288-column segments shard `shard_index` of `shard_count` reports."""
     b, e = C.c_uint64(0), C.c_uint64(0)
     rc = _lib.load().havac_ssv_shard_columns(nsymbols, shard_index, shard_count, C.byref(b), C.byref(e))
+    if rc != 0:
+        raise_for(rc, "bad shard arguments")
+    return b.value, e.value
+
+
+def shard_window(nsymbols: int, nrows: int, shard_index: int, shard_count: int):
+    """-> (first_column, end_column): the whole segments shard `shard_index` of `shard_count` READS (its own columns, the
+    left halo of nrows - 1, a few thousand more for the tiling); what a rank must hold of the database."""
+    b, e = C.c_uint64(0), C.c_uint64(0)
+    rc = _lib.load().havac_ssv_shard_window(nsymbols, nrows, shard_index, shard_count, C.byref(b), C.byref(e))
     if rc != 0:
         raise_for(rc, "bad shard arguments")
     return b.value, e.value

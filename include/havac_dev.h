@@ -220,6 +220,17 @@ int havac_ssv_enqueue(havac_ssv_ctx *ctx, const uint8_t *d_sequence, uint64_t ns
                       uint32_t shard_count, uint64_t *d_hits, uint64_t hit_capacity,
                       const uint32_t *d_abort_flag, void *hip_stream);
 
+/* Optional (no counterpart in the reference: one device holds the whole database there): a rank of a sharded run need
+ * not hold the whole database.  havac_ssv_shard_window tells which columns shard `shard_index` of `shard_count` reads --
+ * its own, the left halo of nrows - 1 columns and a few thousand more for the tiling; whole segments, clipped to the
+ * database (host-only arithmetic).  havac_ssv_set_sequence_window declares that the d_sequence (and separator bitmap)
+ * handed to the next passes hold columns [first_column, first_column + ncolumns) only, byte 0 of the buffer = column
+ * first_column; nsymbols stays the database's total.  A window that does not cover what the shard reads is refused by
+ * havac_ssv_enqueue.  (0, 0) = the buffer holds everything (the default).  C4: 35 MB per rank instead of 250 MB. */
+int havac_ssv_shard_window(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index, uint32_t shard_count,
+                           uint64_t *first_column, uint64_t *end_column);
+int havac_ssv_set_sequence_window(havac_ssv_ctx *ctx, uint64_t first_column, uint64_t ncolumns);
+
 /* Separator bitmap for the next passes (see havac_dev_write_separator_mask); a DEVICE pointer the caller keeps
  * alive, 2-byte aligned, nsymbols/16 bytes; NULL (the default) = none. */
 int havac_ssv_set_separator_mask(havac_ssv_ctx *ctx, const uint8_t *d_pair_bitmap);

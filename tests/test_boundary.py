@@ -138,6 +138,21 @@ def test_shard_arithmetic_is_host_only():
         assert max(widths) - min(widths) <= 12288
 
 
+def test_shard_windows_are_host_only_arithmetic():
+    """havac_ssv_shard_window: whole segments, clipped to the database, containing the shard's own columns and a left
+    halo of at least rows - 1 columns."""
+    from havac_amd.ssv import shard_columns, shard_window
+    n = 900 * 12288
+    for rows in (1, 1024, 20000, 503329):
+        for world in (1, 2, 8):
+            for r in range(world):
+                lo, hi = shard_columns(n, r, world)
+                first, end = shard_window(n, rows, r, world)
+                assert first % 12288 == 0 and end % 12288 == 0 and 0 <= first <= lo and hi <= end <= n
+                assert first == 0 or lo - first >= rows - 1
+                assert lo - first <= rows + 32 + 4096 + 12288 and end - hi <= 4096 + 12288
+
+
 def test_ssv_kernel_resources():
     """What the hot kernel's speed rests on, read from the metadata of the code object inside libhavac_dev.so: 80 VGPRs
     (= six waves per SIMD), no scratch, no register spills, 14 KB of LDS per workgroup.  A change

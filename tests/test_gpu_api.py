@@ -277,6 +277,79 @@ def test_one_handle_over_several_gpus(oracle, tmp_path):
     single.close(); multi.close()
 
 
+def test_gpus_of_a_handle_hold_column_windows_only(oracle):
+    """Several GPUs behind one handle: GPU i keeps only the columns shard i can read (its own + a halo for the tallest model
+    the record format allows, 2^24 - 1 rows), not the whole database -- at the reference's 4 GiB limit eight full copies
+    would be 32 GiB.  40.5 M columns over four parts: the last three windows start well inside the database.  The hit list
+    equals the checker's, with and without a separator bitmap, and the sequence reads back whole."""
+    from havac_amd.hw_client import HavacHwClient
+    nseg = 3300
+    packed = synth.random_packed(nseg * synth.SEGMENT, 77)
+    model, cons = synth.dfam_like_model(300, 78)
+    sym = synth.unpack_2bit(packed)
+    synth.plant_homologs(sym, cons, sym.size, every=50_000, length=250, sub=0.08)
+    packed = synth.pack_2bit(sym)
+    want = oracle.ssv_fast(sym, model, nthreads=8)
+    assert want.size > 2000
+    c = HavacHwClient(deviceIndices=[0, 0, 0, 0])
+    c.writeSequence(packed)
+    c.writePhmm(model)
+    c.invokeHavacSsvAsync()
+    assert c.waitForHavacSsvAsync() == 4
+    assert np.array_equal(c.getHitList(), want)
+    assert np.array_equal(c.readSequence(packed.size), packed)
+    # separators at a few even columns, among them the first and last pair of every shard
+    rng = np.random.default_rng(5)
+    quarter = nseg // 4 * synth.SEGMENT
+    seps = sorted(set((rng.integers(1, sym.size // 2 - 1, size=40) * 2).tolist() + [0, quarter - 2, quarter, 2 * quarter, sym.size - 2]))
+    mask = np.zeros(sym.size // 16, np.uint8)
+    for col in seps:
+        mask[col // 16] |= 1 << ((col // 2) % 8)
+    c.writeSeparatorMask(mask)
+    c.invokeHavacSsvAsync()
+    assert c.waitForHavacSsvAsync() == 4
+    got = c.getHitList()
+    assert np.array_equal(c.readSeparatorMask(mask.size), mask)
+    c.close()
+    single = HavacHwClient()
+    single.writeSequence(packed)
+    single.writeSeparatorMask(mask)
+    single.writePhmm(model)
+    single.invokeHavacSsvAsync()
+    single.waitForHavacSsvAsync()
+    assert np.array_equal(got, single.getHitList()) and got.size != want.size
+    single.close()
+
+
+def test_deferred_start_gives_the_same_hits_and_reports_a_missing_device_late(tmp_path):
+    """Havac::DeferredStart (an addition): the constructor returns at once, the HIP start-up runs under loadPhmm /
+    loadSequence, which wait for the device only when they have something to send."""
+    import ctypes as C
+    from havac_amd import havac
+    from havac_amd.hw_client import LogicError
+    fa, hmm = write_inputs(tmp_path, [60, 300], [5000, 9000, 17], seed=3)
+    lists = []
+    for deferred in (False, True):
+        t0 = time.time()
+        h = havac.Havac(0, 0.02, deferredStart=deferred)
+        built = time.time() - t0
+        if deferred:
+            assert built < 0.05
+            with pytest.raises(LogicError, match="Phmm was not loaded"):
+                h.runHardwareClient()
+        h.loadPhmm(hmm)
+        C.CDLL(None).srand(9)
+        h.loadSequence(fa)
+        h.runHardwareClient()
+        lists.append((h.getHitsFromFinishedRun(), h.rawHits()))
+        h.close()
+    assert len(lists[0][0]) > 10 and lists[0][0] == lists[1][0] and np.array_equal(lists[0][1], lists[1][1])
+    late = havac.Havac(99, 0.02, deferredStart=True)          # no such device: the constructor cannot know yet
+    with pytest.raises(RuntimeError, match="could not open MI355X device 99"):
+        late.loadPhmm(hmm)
+    late.close()
+
+
 def test_native_software_testbench(tmp_path):
     """tests/native/software_testbench.cpp: the reference's C-simulation testbench flow
     (device/test/softwareTestbench.cpp:49-306) in C++ against the C ABI, 2 tests x 3 segments as there."""
@@ -482,3 +555,9 @@ def test_bench_starts_its_own_ranks():
     assert dd["per_rank"][0]["halo_cells"] == 0 and dd["per_rank"][1]["halo_cells"] == 255 * 256 // 2
     assert sum(p["records"] for p in dd["per_rank"]) == d["config"]["hits_per_step"]
     assert all(p["kernel_ms"] > 0 for p in dd["per_rank"])
+    # rank 0 has checked the gathered list before printing: order, counts, columns per rank, the records around the cut
+    parity = dd["parity"]
+    assert parity["ok"] and parity["counts_add_up"] and parity["device_order_no_duplicates"] and parity["ranks_inside_their_columns"]
+    assert len(parity["boundary_stretches"]) == 1 and parity["boundary_stretches"][0]["boundary_column"] == 400 * synth.SEGMENT
+    assert parity["boundary_stretches"][0]["equals_cpu_checker"] and parity["boundary_stretches"][0]["records"] > 0
+    assert d["clock_warmup_passes"] >= 3

@@ -434,3 +434,47 @@ def test_ordering_gives_up_on_a_bucket_too_big_for_lds(torch_dev, oracle):
     want = oracle.ssv_mt(sym, model, cap=1 << 25)
     assert want.size > 1_000_000 and np.array_equal(got, want)
     assert orderings[0][0] == 2 and orderings[0][2] > 16384      # given up for the radix sort; the largest bucket said why
+
+
+def test_a_rank_needs_only_its_window_of_the_database(torch_dev, oracle):
+    """havac_ssv_shard_window / havac_ssv_set_sequence_window: a rank of a sharded run holds the columns its shard READS
+    (its own, the left halo, a few thousand for the tiling) and nothing else -- C4: 31 MB per rank instead of 250 MB.
+    Every shard computed from exactly its window (the rest of the database is not on the device at all) gives the list
+    the whole buffer gives; a window that is too small is refused, not read past."""
+    from havac_amd.ssv import SsvContext, shard_columns, shard_window
+    torch, dev = torch_dev
+    nseg, world = 600, 5
+    ncols = nseg * synth.SEGMENT
+    packed = synth.random_packed(ncols, 314)
+    model, cons = synth.model_collection([700, 90, 2000, 1300], 315)       # 4090 rows: halo of a third of a segment
+    sym = synth.unpack_2bit(packed)
+    synth.plant_homologs(sym, cons, sym.size, every=40_000, length=280, sub=0.08)
+    packed = synth.pack_2bit(sym)
+    want = oracle.ssv_fast(sym, model, nthreads=8, cap=1 << 23)
+    d_phmm = torch.from_numpy(model.reshape(-1)).to(dev)
+    hits = torch.empty(1 << 22, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ctx = SsvContext()
+    parts, held = [], 0
+    for r in range(world):
+        first, end = shard_window(ncols, model.shape[0], r, world)
+        lo, hi = shard_columns(ncols, r, world)
+        assert first % synth.SEGMENT == 0 and end % synth.SEGMENT == 0 and first <= lo and hi <= end <= ncols
+        assert lo - first <= model.shape[0] + 3 * synth.SEGMENT and end - hi <= 2 * synth.SEGMENT      # no more than it needs
+        window = torch.from_numpy(packed[first // 4: end // 4].copy()).to(dev)       # only this much of the database exists on the GPU
+        held += window.numel()
+        ctx.set_sequence_window(first, end - first)
+        ctx.enqueue(window.data_ptr(), ncols, d_phmm.data_ptr(), model.shape[0], hits.data_ptr(), hits.numel(), r, world, 0, stream)
+        n = ctx.finish()
+        parts.append(hits[:n].cpu().numpy().view(np.uint64).copy())
+        del window
+    assert np.array_equal(np.concatenate(parts), want)
+    assert held < 1.3 * packed.size                         # five windows together: little more than one copy
+    # too small a window: one segment short on the left
+    first, end = shard_window(ncols, model.shape[0], 3, world)
+    window = torch.from_numpy(packed[(first + synth.SEGMENT) // 4: end // 4].copy()).to(dev)
+    ctx.set_sequence_window(first + synth.SEGMENT, end - first - synth.SEGMENT)
+    with pytest.raises(ValueError, match="does not cover the columns this shard reads"):
+        ctx.enqueue(window.data_ptr(), ncols, d_phmm.data_ptr(), model.shape[0], hits.data_ptr(), hits.numel(), 3, world, 0, stream)
+    ctx.set_sequence_window(0, 0)
+    ctx.close()
