@@ -112,8 +112,10 @@ struct havac_ssv_ctx {
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     uint64_t* sort_alt = nullptr; size_t sort_alt_count = 0;
     // bucket ordering (hit_order.hip.h): per bucket a count / cursor and an offset, the list of large buckets, shared state
-    uint32_t* bucket_counts = nullptr; uint64_t* bucket_offsets = nullptr; uint32_t* bucket_large = nullptr; size_t bucket_alloc = 0;
-    OrderState* order_state = nullptr;         // device
+    uint32_t* bucket_counts = nullptr; uint32_t* bucket_offsets = nullptr; uint64_t* bucket_chunk_base = nullptr;
+    uint32_t* bucket_large = nullptr; size_t bucket_alloc = 0;
+    OrderState* order_state = nullptr;         // device: two sets used alternately (the last kernel of a pass clears the other set)
+    unsigned order_parity = 0;
     OrderState* h_order_state = nullptr;       // pinned copy the host reads after the ordering
     bool bucket_ordered = false;               // the pending pass went through the bucket ordering (else: the radix sort)
     uint64_t order_count = 0;                  // records of the pending pass's ordering
@@ -161,7 +163,8 @@ extern "C" int havac_ssv_ctx_create(havac_ssv_ctx** out) {
     }
     if (hipHostMalloc(&c->h_count, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return fail(HAVAC_E_NOMEM);
     c->h_count[0] = c->h_count[1] = 0;
-    if (hipMalloc(&c->order_state, sizeof(OrderState)) != hipSuccess) return fail(HAVAC_E_NOMEM);
+    if (hipMalloc(&c->order_state, 2 * sizeof(OrderState)) != hipSuccess) return fail(HAVAC_E_NOMEM);
+    if (hipMemset(c->order_state, 0, 2 * sizeof(OrderState)) != hipSuccess) return fail(HAVAC_E_RUNTIME);
     if (hipHostMalloc(&c->h_order_state, sizeof(OrderState), hipHostMallocDefault) != hipSuccess) return fail(HAVAC_E_NOMEM);
     std::memset(c->h_order_state, 0, sizeof(OrderState));
     for (auto& e : c->ev)
@@ -183,6 +186,7 @@ extern "C" void havac_ssv_ctx_destroy(havac_ssv_ctx* c) {
     if (c->sort_alt) (void)hipFree(c->sort_alt);
     if (c->bucket_counts) (void)hipFree(c->bucket_counts);
     if (c->bucket_offsets) (void)hipFree(c->bucket_offsets);
+    if (c->bucket_chunk_base) (void)hipFree(c->bucket_chunk_base);
     if (c->bucket_large) (void)hipFree(c->bucket_large);
     if (c->order_state) (void)hipFree(c->order_state);
     if (c->h_order_state) (void)hipHostFree(c->h_order_state);
@@ -252,7 +256,7 @@ extern "C" int havac_ssv_set_sequence_window(havac_ssv_ctx* c, uint64_t first_co
 extern "C" int havac_ssv_set_tuning(havac_ssv_ctx* c, int rows_per_block, int tiles_per_item, int block_tails, int ordering) {
     if (!c) return HAVAC_E_ARGUMENT;
     if (c->pending) { c->err = "a pass is in flight: change the tuning between passes"; return HAVAC_E_LOGIC; }
-    if (block_tails > 2 || (rows_per_block > 0 && rows_per_block < 1024)) { c->err = "bad tuning value"; return HAVAC_E_ARGUMENT; }
+    if (block_tails > 2 || ordering > 1 || (rows_per_block > 0 && rows_per_block < 1024)) { c->err = "bad tuning value"; return HAVAC_E_ARGUMENT; }
     c->tune_rows_per_block = rows_per_block; c->tune_tiles_per_item = tiles_per_item; c->tune_block_tails = block_tails;
     c->tune_ordering = ordering;
     return HAVAC_OK;
@@ -546,26 +550,36 @@ static int order_records(havac_ssv_ctx* c, uint64_t* d_hits, uint64_t count, hip
         HIP_TRY(c->err, hipStreamSynchronize(stream));
         if (c->bucket_counts) (void)hipFree(c->bucket_counts);
         if (c->bucket_offsets) (void)hipFree(c->bucket_offsets);
+        if (c->bucket_chunk_base) (void)hipFree(c->bucket_chunk_base);
         if (c->bucket_large) (void)hipFree(c->bucket_large);
-        c->bucket_counts = nullptr; c->bucket_offsets = nullptr; c->bucket_large = nullptr; c->bucket_alloc = 0;
+        c->bucket_counts = nullptr; c->bucket_offsets = nullptr; c->bucket_chunk_base = nullptr; c->bucket_large = nullptr; c->bucket_alloc = 0;
         const size_t want = (size_t)nbuckets + nbuckets / 4 + 1024;
         HIP_TRY(c->err, hipMalloc(&c->bucket_counts, want * sizeof(uint32_t)));
-        HIP_TRY(c->err, hipMalloc(&c->bucket_offsets, (want + 1) * sizeof(uint64_t)));
+        HIP_TRY(c->err, hipMalloc(&c->bucket_offsets, want * sizeof(uint32_t)));
+        HIP_TRY(c->err, hipMalloc(&c->bucket_chunk_base, (want / kScanChunk + 2) * sizeof(uint64_t)));
         HIP_TRY(c->err, hipMalloc(&c->bucket_large, want * sizeof(uint32_t)));
+        HIP_TRY(c->err, hipMemset(c->bucket_counts, 0, want * sizeof(uint32_t)));     // once: every pass leaves the counts at zero
         c->bucket_alloc = want;
     }
-    HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, (size_t)nbuckets * sizeof(uint32_t), stream));
-    HIP_TRY(c->err, hipMemsetAsync(c->order_state, 0, sizeof(OrderState), stream));
-    const unsigned pass_blocks = (unsigned)std::min<uint64_t>((count + 255) / 256, (uint64_t)c->resident_blocks * 8);
+    const uint32_t nchunks = (nbuckets + kScanChunk - 1) / kScanChunk;
+    // (no fills and no copies around the five kernels: the sorters leave every count they consumed at zero, the last kernel
+    // clears the other set of state words for the next pass and writes this pass's outcome into pinned host memory)
+    OrderState* const state = c->order_state + (c->order_parity & 1u);
+    OrderState* const next_state = c->order_state + ((c->order_parity + 1u) & 1u);
+    c->order_parity++;
+    const unsigned pass_blocks = (unsigned)std::min<uint64_t>((count + 1023) / 1024, (uint64_t)c->resident_blocks * 2);     // up to 1024 keys per workgroup and round
     hipLaunchKernelGGL(ssv_bucket_count, dim3(pass_blocks), dim3(256), 0, stream, (const uint64_t*)d_hits, count, shift, base, c->bucket_counts);
-    hipLaunchKernelGGL(ssv_bucket_scan, dim3(1), dim3(1024), 0, stream, c->bucket_counts, nbuckets, c->bucket_offsets, c->bucket_large, c->order_state);
+    hipLaunchKernelGGL(ssv_bucket_scan, dim3(nchunks), dim3(256), 0, stream, c->bucket_counts, nbuckets, c->bucket_offsets, c->bucket_chunk_base,
+                       nchunks, c->bucket_large, state);
     hipLaunchKernelGGL(ssv_bucket_scatter, dim3(pass_blocks), dim3(256), 0, stream, (const uint64_t*)d_hits, count, shift, base,
-                       (const uint64_t*)c->bucket_offsets, c->bucket_counts, c->sort_alt, (const OrderState*)c->order_state);
-    hipLaunchKernelGGL(ssv_bucket_sort_small, dim3(std::min<uint32_t>(nbuckets, 1u << 30)), dim3(256), 0, stream, (const uint64_t*)c->sort_alt, d_hits,
-                       (const uint64_t*)c->bucket_offsets, nbuckets, shift, base, row_bits, (const OrderState*)c->order_state);
-    hipLaunchKernelGGL(ssv_bucket_sort_large, dim3(256), dim3(1024), 0, stream, (const uint64_t*)c->sort_alt, d_hits,
-                       (const uint64_t*)c->bucket_offsets, (const uint32_t*)c->bucket_large, shift, base, row_bits, (const OrderState*)c->order_state);
-    HIP_TRY(c->err, hipMemcpyAsync(c->h_order_state, c->order_state, sizeof(OrderState), hipMemcpyDeviceToHost, stream));
+                       (const uint64_t*)c->bucket_chunk_base, (const uint32_t*)c->bucket_offsets, c->bucket_counts, c->sort_alt,
+                       (const OrderState*)state);
+    hipLaunchKernelGGL(ssv_bucket_sort_small, dim3(std::min<uint32_t>((nbuckets + 3) / 4, 1u << 24)), dim3(256), 0, stream, (const uint64_t*)c->sort_alt, d_hits,
+                       (const uint64_t*)c->bucket_chunk_base, (const uint32_t*)c->bucket_offsets, c->bucket_counts, nbuckets,
+                       shift, base, row_bits, (const OrderState*)state);
+    hipLaunchKernelGGL(ssv_bucket_sort_large, dim3(128), dim3(256), 0, stream, (const uint64_t*)c->sort_alt, d_hits,
+                       (const uint64_t*)c->bucket_chunk_base, (const uint32_t*)c->bucket_offsets, c->bucket_counts,
+                       (const uint32_t*)c->bucket_large, shift, base, row_bits, (const OrderState*)state, next_state, c->h_order_state);
     HIP_TRY(c->err, hipGetLastError());
     c->bucket_ordered = true;
     c->last_order_buckets = nbuckets;
