@@ -118,6 +118,7 @@ struct havac_ssv_ctx {
     unsigned order_parity = 0;
     OrderState* h_order_state = nullptr;       // pinned copy the host reads after the ordering
     bool bucket_ordered = false;               // the pending pass went through the bucket ordering (else: the radix sort)
+    bool order_dirty = false;                  // an ordering was enqueued and never seen to finish: its counts and state words cannot be trusted
     uint64_t order_count = 0;                  // records of the pending pass's ordering
     uint64_t first_segment = 0, nsegments = 0; // the shard's segments (bucket numbering)
     int tune_ordering = -1;                    // -1 / 1: bucket ordering, 0: always the radix sort (experiments, tests)
@@ -169,6 +170,8 @@ extern "C" int havac_ssv_ctx_create(havac_ssv_ctx** out) {
     std::memset(c->h_order_state, 0, sizeof(OrderState));
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+    // the fills above ran on the null stream; passes run on streams of the caller's, possibly non-blocking ones
+    if (hipDeviceSynchronize() != hipSuccess) return fail(HAVAC_E_RUNTIME);
     *out = c;
     return HAVAC_OK;
 }
@@ -558,19 +561,27 @@ static int order_records(havac_ssv_ctx* c, uint64_t* d_hits, uint64_t count, hip
         HIP_TRY(c->err, hipMalloc(&c->bucket_offsets, want * sizeof(uint32_t)));
         HIP_TRY(c->err, hipMalloc(&c->bucket_chunk_base, (want / kScanChunk + 2) * sizeof(uint64_t)));
         HIP_TRY(c->err, hipMalloc(&c->bucket_large, want * sizeof(uint32_t)));
-        HIP_TRY(c->err, hipMemset(c->bucket_counts, 0, want * sizeof(uint32_t)));     // once: every pass leaves the counts at zero
+        // once: every pass leaves the counts at zero.  (On the pass's own stream: a null-stream hipMemset is not ordered against a
+        // non-blocking stream, and the count kernel below would race with it.)
+        HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, want * sizeof(uint32_t), stream));
         c->bucket_alloc = want;
     }
     const uint32_t nchunks = (nbuckets + kScanChunk - 1) / kScanChunk;
     // (no fills and no copies around the five kernels: the sorters leave every count they consumed at zero, the last kernel
-    // clears the other set of state words for the next pass and writes this pass's outcome into pinned host memory)
+    // clears the other set of state words for the next pass and writes this pass's outcome into pinned host memory -- unless
+    // the ordering before this one was never seen to finish: then everything starts from zero)
+    if (c->order_dirty) {
+        HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, c->bucket_alloc * sizeof(uint32_t), stream));
+        HIP_TRY(c->err, hipMemsetAsync(c->order_state, 0, 2 * sizeof(OrderState), stream));
+    }
+    c->order_dirty = true;
     OrderState* const state = c->order_state + (c->order_parity & 1u);
     OrderState* const next_state = c->order_state + ((c->order_parity + 1u) & 1u);
     c->order_parity++;
     const unsigned pass_blocks = (unsigned)std::min<uint64_t>((count + 1023) / 1024, (uint64_t)c->resident_blocks * 2);     // up to 1024 keys per workgroup and round
     hipLaunchKernelGGL(ssv_bucket_count, dim3(pass_blocks), dim3(256), 0, stream, (const uint64_t*)d_hits, count, shift, base, c->bucket_counts);
     hipLaunchKernelGGL(ssv_bucket_scan, dim3(nchunks), dim3(256), 0, stream, c->bucket_counts, nbuckets, c->bucket_offsets, c->bucket_chunk_base,
-                       nchunks, c->bucket_large, state);
+                       nchunks, c->bucket_large, state, count);
     hipLaunchKernelGGL(ssv_bucket_scatter, dim3(pass_blocks), dim3(256), 0, stream, (const uint64_t*)d_hits, count, shift, base,
                        (const uint64_t*)c->bucket_chunk_base, (const uint32_t*)c->bucket_offsets, c->bucket_counts, c->sort_alt,
                        (const OrderState*)state);
@@ -617,10 +628,13 @@ extern "C" int havac_ssv_finish_end(havac_ssv_ctx* c, uint64_t* hit_count_out) {
     HIP_TRY(c->err, hipEventSynchronize(c->ev[3]));
     c->last_order_path = c->bucket_ordered ? 1 : 0;
     if (c->bucket_ordered) {
+        c->order_dirty = false;                // the last kernel of the ordering has run
         c->last_order_largest = c->h_order_state->largest;
         if (c->h_order_state->oversized) {
-            // a bucket too big for an LDS sort: nothing was moved (hit_order.hip.h) -- this pass takes the generic path
+            // a bucket too big for an LDS sort (or counts left behind by a pass that was cut short): nothing was moved
+            // (hit_order.hip.h) -- this pass takes the generic path, and the counts start from zero again
             const hipStream_t order = c->order_stream ? c->order_stream : c->stream;
+            HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, c->bucket_alloc * sizeof(uint32_t), order));
             int rc = order_by_radix_sort(c, c->d_hits, c->order_count, order);
             if (rc) return rc;
             HIP_TRY(c->err, hipEventRecord(c->ev[3], order));

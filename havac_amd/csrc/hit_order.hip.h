@@ -99,7 +99,7 @@ void ssv_bucket_count(const uint64_t* __restrict__ keys, uint64_t n, uint32_t sh
 // chunk_base[b / kScanChunk] + local_offsets[b].  One launch whatever the number of buckets.
 __global__ __launch_bounds__(256)
 void ssv_bucket_scan(uint32_t* __restrict__ counts, uint32_t nbuckets, uint32_t* __restrict__ local_offsets, uint64_t* __restrict__ chunk_base,
-                     uint32_t nchunks, uint32_t* __restrict__ large_list, OrderState* __restrict__ state) {
+                     uint32_t nchunks, uint32_t* __restrict__ large_list, OrderState* __restrict__ state, uint64_t nrecords) {
     __shared__ uint32_t tile[kScanChunk];
     __shared__ uint32_t wave_sum[4];
     __shared__ uint32_t last_block;
@@ -173,7 +173,14 @@ void ssv_bucket_scan(uint32_t* __restrict__ counts, uint32_t nbuckets, uint32_t*
         const uint32_t c = t * per + k;
         if (c < nchunks) { const uint64_t mine_total = chunk_base[c]; chunk_base[c] = at; at += mine_total; }
     }
-    if (t == 255) { chunk_base[nchunks] = part[255]; state->chunks_done = 0; }
+    if (t == 255) {
+        chunk_base[nchunks] = part[255];
+        state->chunks_done = 0;
+        // The counts must add up to the records of this pass.  They do unless a pass before this one was cut short (a HIP error
+        // between its kernels) and left counts behind: then nothing is moved -- offsets from such counts would point outside the
+        // buffers -- and the host clears the counts and orders this pass with the radix sort (`oversized` = 2).
+        if (part[255] != nrecords) atomicOr(&state->oversized, 2u);
+    }
 }
 
 __device__ __forceinline__ uint64_t bucket_begin(const uint64_t* __restrict__ chunk_base, const uint32_t* __restrict__ local_offsets, uint32_t b) {
