@@ -1,0 +1,44 @@
+"""python tools/collect_profiles.py <tag in gpurun_out> <tag in profiles> "<note>": copies what tools/measure_round.sh left under
+gpurun_out/ into profiles/ -- bench lines, the rocprofv3 --kernel-trace --stats summaries (kernel names shortened, the command
+and the note in a header line), the PMC summaries, the model-height sweep, the end-to-end series, the PCIe-inclusive rate."""
+import csv
+import os
+import shutil
+import sys
+
+src_tag, dst_tag, note = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "")
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+
+
+def copy(src, dst):
+    if os.path.isfile(os.path.join(G, src)) and os.path.getsize(os.path.join(G, src)):
+        shutil.copyfile(os.path.join(G, src), os.path.join(P, dst))
+        print("profiles/" + dst)
+
+
+for w in ("c2", "c3", "c5"):
+    copy(f"{src_tag}_bench_{w}.json", f"{dst_tag}_bench_{w}.json")
+    copy(f"{src_tag}_bench_{w}_under_rocprof.json", f"{dst_tag}_bench_{w}_under_rocprof.json")
+    stats = os.path.join(G, f"{src_tag}_prof_{w}", f"{w}_kernel_stats.csv")
+    if os.path.isfile(stats):
+        rows = list(csv.reader(open(stats)))
+        out = os.path.join(P, f"{dst_tag}_kernel_stats_{w}.csv")
+        with open(out, "w") as f:
+            f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {w} --no-pmc --no-cpu-baseline (MI355X; {note}); "
+                    "every launch of the run is in the average, warm-up included; kernel names shortened\n")
+            for r in rows:
+                r[0] = r[0].split("(")[0]
+                f.write(",".join(r) + "\n")
+        print("profiles/" + os.path.basename(out))
+    pmc = os.path.join(G, f"pmc_{src_tag}_{w}_summary.csv")
+    if os.path.isfile(pmc):
+        with open(os.path.join(P, f"{dst_tag}_pmc_{w}.csv"), "w") as f:
+            f.write(f"# bash tools/pmc_passes.sh {w} dfam (one rocprofv3 --pmc pass per group; tools/pmc_probe.py: 3 launches of the workload "
+                    f"through the handle API); averages per launch of havac::ssv_diag_kernel; {note}\n")
+            f.write(open(pmc).read())
+        print(f"profiles/{dst_tag}_pmc_{w}.csv")
+copy(f"{src_tag}_bench_c4_one_gpu.json", f"{dst_tag}_bench_c4_one_gpu.json")
+copy(f"{src_tag}_rows_sweep.txt", f"{dst_tag}_rows_sweep_kernel_ms.txt")
+copy(f"{src_tag}_e2e_series.txt", f"{dst_tag}_e2e_series_51Mbp.txt")
+copy(f"{src_tag}_pcie_inclusive_c2.txt", f"{dst_tag}_pcie_inclusive_c2.txt")
