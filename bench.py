@@ -383,8 +383,9 @@ def main():
                          "0 = 3 for passes up to 1e12 cells per GPU (C2 is 1e11), else 1: ordering tens of millions of "
                          "records next to the following kernel slows that kernel by more than it hides "
                          "(C3 shape: 303 vs 267 ms per step)")
-    ap.add_argument("--tuning", default="", help="experiments: rows_per_block,tiles_per_item,block_tails,ordering for "
-                    "havac_ssv_set_tuning (-1 = the library's own rule), e.g. --tuning=-1,-1,-1,0 orders with the radix sort")
+    ap.add_argument("--tuning", default="", help="experiments: rows_per_block,tiles_per_item,block_tails,ordering[,parts_log2,"
+                    "split_rounds_x4,short_rows,guide] for havac_ssv_set_tuning / havac_ssv_set_split_tuning (-1 = the library's own "
+                    "rule), e.g. --tuning=-1,-1,-1,0 orders with the radix sort")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="N > 1: skip rank 0's check of the gathered list (distributed.parity)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")

@@ -26,6 +26,7 @@ SIGNATURES = {
     "havac_dev_device_count": (C.c_uint32, [_vp]),
     "havac_dev_destroy": (None, [_vp]),
     "havac_dev_set_hit_capacity": (C.c_int, [_vp, C.c_uint64]),
+    "havac_dev_set_tuning": (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_uint32]),
     "havac_dev_write_sequence": (C.c_int, [_vp, _u8p, C.c_uint64]),
     "havac_dev_write_phmm": (C.c_int, [_vp, _i8p, C.c_uint64]),
     "havac_dev_write_separator_mask": (C.c_int, [_vp, _u8p, C.c_uint64]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     "havac_ssv_finish_begin": (C.c_int, [_vp]),
     "havac_ssv_finish_end": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "havac_ssv_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "havac_ssv_set_split_tuning": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "havac_ssv_last_ordering": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "havac_ssv_sort_hits": (C.c_int, [_vp, C.c_void_p, C.c_uint64, C.c_void_p]),
     "havac_ssv_last_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

@@ -93,6 +93,70 @@ void shard_window(uint64_t nsymbols, uint32_t nrows, uint64_t col_begin, uint64_
     *end = std::min<uint64_t>(nsymbols, (hi + HAVAC_SEGMENT_COLUMNS - 1) / HAVAC_SEGMENT_COLUMNS * HAVAC_SEGMENT_COLUMNS);
 }
 
+// ---- partitions of a launch's units ----------------------------------------------------------------------------------------
+struct PartitionKey {
+    uint64_t nsymbols = 0; uint32_t nrows = 0; uint64_t col_begin = 0, col_end = 0; uint32_t tb = 0, te = 0, per_item = 0, parts_log2 = 0;
+    bool operator==(const PartitionKey& o) const {
+        return nsymbols == o.nsymbols && nrows == o.nrows && col_begin == o.col_begin && col_end == o.col_end && tb == o.tb && te == o.te &&
+               per_item == o.per_item && parts_log2 == o.parts_log2;
+    }
+};
+// rows of tile `tile` (of the whole tiling) that the kernel walks: ssv_diag_body's p_lo, p_hi
+inline uint64_t tile_rows(const Tiling& t, uint32_t tile, int64_t col_end) {
+    const int64_t d0 = t.first_diag + (int64_t)tile * kTileDiags;
+    const int64_t lo = std::min<int64_t>(std::max<int64_t>(-d0 - kTileDiags, 0), t.nrows_padded);
+    const int64_t hi = std::min<int64_t>(std::max<int64_t>(col_end - d0, 0), t.nrows_padded);
+    return hi > lo ? (uint64_t)(hi - lo) : 0u;
+}
+// part_begin[0 .. nparts]: unit numbers; partition k = units [part_begin[k], part_begin[k+1]) holds about 1/nparts of the rows
+void plan_partitions(const Tiling& t, uint32_t tile_begin, uint32_t ntiles, int64_t col_end, uint32_t per_item, uint32_t nparts, uint32_t* part_begin) {
+    const uint32_t nunits = (ntiles + per_item - 1) / per_item;
+    // (+ a constant per tile: its prologue and the step behind its last chunk -- what short tiles mostly consist of)
+    auto unit_work = [&](uint32_t u) {
+        uint64_t w = 0;
+        for (uint32_t g = 0; g < per_item && u * per_item + g < ntiles; g++) w += tile_rows(t, tile_begin + u * per_item + g, col_end) + 16;
+        return w;
+    };
+    uint64_t total = 0;
+    for (uint32_t u = 0; u < nunits; u++) total += unit_work(u);
+    part_begin[0] = 0;
+    uint64_t seen = 0;
+    uint32_t k = 1;
+    for (uint32_t u = 0; u < nunits && k < nparts; u++) {
+        seen += unit_work(u);
+        while (k < nparts && seen * nparts >= total * k) part_begin[k++] = u + 1;
+    }
+    while (k <= nparts) part_begin[k++] = nunits;
+    part_begin[nparts] = nunits;
+}
+
+// ---- row cuts of tall tiles ---------------------------------------------------------------------------------------------
+// A cut tile is handed from wave to wave (ssv_kernels.hip.h, "work distribution"): every cut costs 2 x 4 KB through memory, and
+// only the END of a launch needs fine grains.  So the blocks taper: each takes 1/guide of the rows that are left (whole
+// chunk-flag words of 1024 rows), never less than `short_rows`, and a remainder below half of that joins the last block.
+constexpr uint32_t kShortRows = 4096;       // finest row block
+constexpr uint32_t kCutGuide = 2;           // a block takes 1/kCutGuide of the remaining rows
+constexpr uint32_t kSplitRoundsX4 = 6;      // tiles of the last 1.5 rounds of wave slots are cut
+constexpr uint32_t kChainRows = 16384;      // tallest uniform row block of a launch whose every tile is cut (fewer tiles than that many wave slots)
+struct RowCuts { uint32_t ncuts = 0, uniform_rows = 0, nrow_blocks = 0; uint32_t cut[kMaxRowCuts + 1] = {}; };
+RowCuts plan_row_cuts(uint32_t nrows_padded, uint32_t short_rows, uint32_t guide) {
+    RowCuts r;
+    short_rows = std::max(1024u, short_rows / 1024u * 1024u);
+    guide = std::max(2u, guide);
+    uint32_t at = 0;
+    while (at < nrows_padded && r.ncuts < (uint32_t)kMaxRowCuts) {
+        const uint32_t left = nrows_padded - at;
+        uint32_t h = std::max(short_rows, (left / guide + 1023u) / 1024u * 1024u);
+        if (left < h + short_rows / 2) h = left;
+        at += h;
+        r.cut[++r.ncuts] = std::min(at, nrows_padded);
+    }
+    // (what the table does not reach -- a slow taper over a tall model -- goes on in uniform blocks of `short_rows` rows)
+    r.uniform_rows = short_rows;
+    r.nrow_blocks = r.ncuts + (at < nrows_padded ? (nrows_padded - at + short_rows - 1) / short_rows : 0u);
+    return r;
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -131,6 +195,9 @@ struct havac_ssv_ctx {
     uint64_t window_first = 0, window_columns = 0;   // the caller's sequence buffer holds only these columns (0, 0: all of them)
     // experiment knobs (havac_ssv_set_tuning): -1 = the library decides
     int tune_rows_per_block = -1, tune_tiles_per_item = -1, tune_block_tails = -1;
+    // havac_ssv_set_split_tuning: partitions (-1: the library decides), rounds of wave slots whose tiles are cut (x4), finest row block, taper
+    PartitionKey part_key{}; uint32_t part_begin[9] = {};            // the partitions of the last launch's shape (plan_partitions)
+    int tune_parts_log2 = -1; uint32_t tune_split_rounds_x4 = kSplitRoundsX4, tune_short_rows = kShortRows, tune_guide = kCutGuide;
     // the pass enqueue() started and finish() completes
     bool pending = false, ordering = false;    // enqueue() done; finish_begin() done
     uint64_t found = 0;
@@ -265,6 +332,17 @@ extern "C" int havac_ssv_set_tuning(havac_ssv_ctx* c, int rows_per_block, int ti
     return HAVAC_OK;
 }
 
+extern "C" int havac_ssv_set_split_tuning(havac_ssv_ctx* c, int parts_log2, int split_rounds_x4, int short_rows, int guide) {
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (c->pending) { c->err = "a pass is in flight: change the tuning between passes"; return HAVAC_E_LOGIC; }
+    if (parts_log2 > 3 || (short_rows >= 0 && short_rows < 1024) || guide == 0 || guide == 1 || guide > 16) { c->err = "bad tuning value"; return HAVAC_E_ARGUMENT; }
+    c->tune_parts_log2 = parts_log2 < 0 ? -1 : parts_log2;
+    c->tune_split_rounds_x4 = split_rounds_x4 < 0 ? kSplitRoundsX4 : (uint32_t)split_rounds_x4;
+    c->tune_short_rows = short_rows < 0 ? kShortRows : (uint32_t)short_rows / 1024u * 1024u;
+    c->tune_guide = guide < 0 ? kCutGuide : (uint32_t)guide;
+    return HAVAC_OK;
+}
+
 extern "C" int havac_ssv_last_ordering(havac_ssv_ctx* c, int* path, uint32_t* nbuckets, uint32_t* largest_bucket) {
     if (!c) return HAVAC_E_ARGUMENT;
     if (path) *path = c->last_order_path;
@@ -365,19 +443,44 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     SsvRare L{};          // the kernel's first argument: tiling, hit queue, hand-off buffers (read from the kernarg segment on demand)
     L.first_diag = t.first_diag; L.tile_begin = tb; L.ntiles = te - tb;
     L.col_end = (int64_t)col_end;
-    // Row blocks (ssv_kernels.hip.h, "work distribution"): tiles taller than a block are cut into blocks of
-    // kRowsPerBlock rows when there are fewer of them than kSplitBelowRounds rounds of wave slots (measured, kernel
-    // only: C3 as stated 42.4 -> 54.0 TCUPS, C5 53.0 -> 54.6; blocks of 4096 / 16384 rows: 53.6 / 53.6 and 54.0 / 54.7).  (Cutting SHORT
-    // tiles to fill the last round -- C2 is 9.54 rounds -- does not pay: 2, 3, 4 row blocks per 1024-row tile took 2.20,
-    // 3.22, 4.5 ms against 2.02: a hand-off per 57 us of work, with its release and acquire, costs more than the idle slots.)
+    // How the tiles are handed out (ssv_kernels.hip.h, "items"): eight partitions of adjacent tiles, one per XCD under the
+    // observed round-robin placement; whole tiles first; where tiles are tall, the LAST tiles of every partition -- the last
+    // kSplitRounds rounds of wave slots of the launch -- are cut by rows, the cuts getting finer towards the model's end
+    // (plan_row_cuts), so that the launch ends everywhere at about the same time.  Round 2 cut EVERY tile into blocks of 8192
+    // rows: the same balance, but a hand-off (2 x 4 KB through memory) per 8192 x 2048 cells was 7-9 x the bytes the problem needs on
+    // C3 and C5.  (Cutting SHORT tiles to fill the last round -- C2 is 9.54 rounds -- does not pay: 2, 3, 4 row blocks per
+    // 1024-row tile took 2.20, 3.22, 4.5 ms against 2.02.)
     const uint64_t slots = (uint64_t)c->resident_blocks * kWavesPerBlock;
-    uint32_t rows_per_block = 0;
-    if (te > tb && t.nrows_padded >= kRowsPerBlock + 1024 && L.ntiles < kSplitBelowRounds * slots) rows_per_block = kRowsPerBlock;
-    if (c->tune_rows_per_block >= 0) {                                        // experiments (havac_ssv_set_tuning): 0 = never split
-        rows_per_block = (uint32_t)c->tune_rows_per_block / 1024u * 1024u;    // whole chunk-flag words
-        if (rows_per_block >= t.nrows_padded) rows_per_block = 0;
+    L.parts_log2 = L.ntiles >= 64 ? 3u : 0u;
+    if (c->tune_parts_log2 >= 0) L.parts_log2 = (uint32_t)c->tune_parts_log2;
+    const uint32_t nparts = 1u << L.parts_log2;
+    RowCuts cuts{};
+    uint32_t split_units = 0;
+    if (te > tb && c->tune_rows_per_block < 0 && t.nrows_padded >= 2 * c->tune_short_rows) {
+        split_units = (uint32_t)((c->tune_split_rounds_x4 * slots / 4 + nparts - 1) / nparts);
+        if ((uint64_t)split_units * nparts >= L.ntiles) {
+            // Fewer tiles than wave slots, or hardly more (C3 as stated: 5,130 tiles of 503,329 rows): every tile is a chain of row
+            // blocks that runs from the launch's start to its end, and what keeps the chains in step is that the waves which WAIT
+            // (there are more slots than chains) change places often.  Uniform blocks, then -- a taper that opens with half the rows
+            // leaves the same SIMDs overbooked for half the launch (measured on C3: 97.3 ms against 89.6) -- of about 1/16 of the
+            // model: blocks of 8192 rows (round 2) balance 1.3 % better than blocks of 32768 and move 2.4 x the bytes.
+            const uint32_t rows = std::min(std::max((t.nrows_padded / 16 + 1023u) / 1024u * 1024u, 2 * c->tune_short_rows), kChainRows);
+            cuts.ncuts = 0; cuts.cut[0] = 0; cuts.uniform_rows = rows;
+            cuts.nrow_blocks = (t.nrows_padded + rows - 1) / rows;
+            split_units = 0xffffffffu;
+        } else {
+            cuts = plan_row_cuts(t.nrows_padded, c->tune_short_rows, c->tune_guide);
+        }
+    } else if (te > tb && c->tune_rows_per_block > 0) {                       // experiments and tests (havac_ssv_set_tuning): uniform blocks, every tile cut
+        const uint32_t rows_per_block = (uint32_t)c->tune_rows_per_block / 1024u * 1024u;    // whole chunk-flag words
+        if (rows_per_block && rows_per_block < t.nrows_padded) {
+            split_units = 0xffffffffu;
+            cuts.ncuts = 0; cuts.cut[0] = 0; cuts.uniform_rows = rows_per_block;
+            cuts.nrow_blocks = (t.nrows_padded + rows_per_block - 1) / rows_per_block;
+        }
     }
-    const bool split = rows_per_block != 0;
+    if (cuts.nrow_blocks < 2) split_units = 0;
+    const bool split = split_units != 0;
     // A wave can walk several adjacent tiles (ssv_kernels.hip.h, "items"; havac_ssv_set_tuning).  Built for short models, whose
     // blocks queued up at the hit counter; the block tails removed that queue altogether, and with them groups of two
     // tiles are 1-3 % SLOWER than single tiles (fewer, longer items balance worse): off unless forced.
@@ -385,30 +488,53 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     if (c->tune_tiles_per_item >= 1 && !split) tiles_per_item = (uint32_t)c->tune_tiles_per_item;      // experiments
     L.tiles_per_item = tiles_per_item;
     uint32_t nblocks = 0;
+    uint32_t largest_item_rows = t.nrows_padded;
     if (te > tb) {
-        L.nitems = (L.ntiles + tiles_per_item - 1) / tiles_per_item;
+        L.split_units = split_units;
+        L.nrow_blocks = split ? cuts.nrow_blocks : 1u;
+        L.ncuts = cuts.ncuts; L.uniform_rows = cuts.uniform_rows;
+        for (uint32_t i = 0; i <= kMaxRowCuts; i++) L.row_cut[i] = cuts.cut[i];
+        // partitions: runs of units of about equal work (a tile's work = its rows inside the matrix and the shard's columns: the
+        // tiles at the matrix's two ends are triangles -- with C3's 503,329 rows the first and the last eighth of the tiles would
+        // hold 19 % less work than the others); kept from pass to pass while the shape stays the same
+        {
+            const PartitionKey key{nsymbols, nrows, col_begin, col_end, tb, te, tiles_per_item, L.parts_log2};
+            if (!(key == c->part_key)) {
+                plan_partitions(t, tb, te - tb, (int64_t)col_end, tiles_per_item, nparts, c->part_begin);
+                c->part_key = key;
+            }
+            for (uint32_t k = 0; k <= 8; k++) L.part_begin[k] = c->part_begin[std::min(k, nparts)];
+        }
+        // blocks: every partition gets as many as its largest sibling needs (a block without items leaves at once)
+        uint64_t most_items = 0;
+        bool any_whole = false;
+        for (uint32_t k = 0; k < nparts; k++) {
+            const uint64_t mine = L.part_begin[k + 1] - L.part_begin[k], cut_units = std::min<uint64_t>(split_units, mine);
+            most_items = std::max(most_items, (mine - cut_units) + cut_units * L.nrow_blocks);
+            any_whole = any_whole || mine > cut_units;
+        }
+        const uint64_t blocks64 = (most_items + kWavesPerBlock - 1) / kWavesPerBlock * nparts;
+        if (blocks64 * (64 * kWavesPerBlock) >= (1ull << 32)) {      // a dispatch counts its work-items in 32 bits
+            c->err = "too many tiles x row blocks for one launch (" + std::to_string(blocks64) + " workgroups)";
+            return HAVAC_E_LENGTH;
+        }
+        nblocks = (uint32_t)blocks64;
         if (split) {
+            if (!any_whole) {
+                largest_item_rows = cuts.uniform_rows;
+                for (uint32_t i = 0; i < cuts.ncuts; i++) largest_item_rows = std::max(largest_item_rows, cuts.cut[i + 1] - cuts.cut[i]);
+            }
             if (c->block_flag_tiles < L.ntiles) {
+                HIP_TRY(c->err, hipStreamSynchronize(stream));        // an earlier pass on this stream may still use the old buffers
                 if (c->block_flags) (void)hipFree(c->block_flags);
                 if (c->block_state) (void)hipFree(c->block_state);
                 c->block_flags = c->block_state = nullptr; c->block_flag_tiles = c->block_state_tiles = 0;
                 HIP_TRY(c->err, hipMalloc(&c->block_flags, (size_t)L.ntiles * sizeof(uint32_t)));
-                HIP_TRY(c->err, hipMalloc(&c->block_state, (size_t)L.ntiles * kRegs * 64 * sizeof(uint32_t)));
+                HIP_TRY(c->err, hipMalloc(&c->block_state, (size_t)L.ntiles * (kRegs / 2) * 64 * sizeof(uint32_t)));
                 c->block_flag_tiles = c->block_state_tiles = L.ntiles;
             }
-            L.rows_per_block = rows_per_block;
-            const uint64_t nblocks_rows = (t.nrows_padded + rows_per_block - 1) / rows_per_block;
-            if (nblocks_rows * L.ntiles >= (1ull << 26)) { c->err = "too many tiles x row blocks for one launch"; return HAVAC_E_LENGTH; }
-            L.nitems = (uint32_t)(nblocks_rows * L.ntiles);
-        }
-        if ((uint64_t)L.nitems * 64 >= (1ull << 32)) {      // a dispatch counts its work-items in 32 bits
-            c->err = "too many tiles x row blocks for one launch (" + std::to_string(L.nitems) + " items)";
-            return HAVAC_E_LENGTH;
-        }
-        nblocks = (uint32_t)(((uint64_t)L.nitems + kWavesPerBlock - 1) / kWavesPerBlock);
-        if (split) {
             HIP_TRY(c->err, hipMemsetD32Async((hipDeviceptr_t)c->block_flags, 0, (size_t)L.ntiles, stream));
-            HIP_TRY(c->err, hipMemsetD32Async((hipDeviceptr_t)c->tickets, 0, kTicketStride, stream));
+            HIP_TRY(c->err, hipMemsetD32Async((hipDeviceptr_t)c->tickets, 0, kTicketCounters * kTicketStride, stream));
         }
     }
     HIP_TRY(c->err, hipEventRecord(c->ev[1], stream));
@@ -423,7 +549,7 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         // block of C2 (1024 rows) lives 200 us and loses nothing to the one atomic at its end, while its tail would cross
         // HBM three times instead of once (measured: the same step time, 43.8 against 39.2 MB of traffic per launch) -- and
         // the buffer stays below 128 MB
-        const uint32_t item_rows = split ? rows_per_block : t.nrows_padded;
+        const uint32_t item_rows = largest_item_rows;
         bool use_tails = item_rows <= 512 && (uint64_t)nblocks * kTailSlots * sizeof(uint64_t) <= (128ull << 20);
         if (c->tune_block_tails >= 0)      // experiments: 0 = off, 1 = the default rule, 2 = on whatever the height of an item
             use_tails = c->tune_block_tails == 2 ? (uint64_t)nblocks * kTailSlots * sizeof(uint64_t) <= (128ull << 20) : use_tails && c->tune_block_tails != 0;
@@ -793,6 +919,18 @@ extern "C" int havac_dev_set_hit_capacity(havac_dev* d, uint64_t max_hits) {
     if (!d || max_hits == 0) return HAVAC_E_ARGUMENT;
     if (d->has_run && !d->finished) { d->err = "cannot resize the hit buffer during a run"; return HAVAC_E_LOGIC; }
     return dev_alloc_hits(d, max_hits);
+}
+
+extern "C" int havac_dev_set_tuning(havac_dev* d, const int32_t* values, uint32_t count) {
+    if (!d || (!values && count)) return HAVAC_E_ARGUMENT;
+    if (d->has_run && !d->finished) { d->err = "cannot change the tuning during a run"; return HAVAC_E_LOGIC; }
+    int v[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    for (uint32_t i = 0; i < count && i < 8; i++) v[i] = values[i];
+    for (DevicePart& p : d->parts) {
+        if (int rc = havac_ssv_set_tuning(p.ctx, v[0], v[1], v[2], v[3])) { d->err = havac_ssv_ctx_last_error(p.ctx); return rc; }
+        if (int rc = havac_ssv_set_split_tuning(p.ctx, v[4], v[5], v[6], v[7])) { d->err = havac_ssv_ctx_last_error(p.ctx); return rc; }
+    }
+    return HAVAC_OK;
 }
 
 // copies a host buffer to the same-named device buffer of every GPU of the handle

@@ -97,6 +97,7 @@ constexpr uint32_t kCrossedBits = 0x00010001u;    // bit 0 of either cell: set o
 constexpr uint32_t kOutsideReset = 0x80008000u;   // match word "score -128" for both cells (separator pairs: two of them reset a diagonal)
 constexpr uint32_t kOutsideNeutral = 0u;          // match word "score 0": columns outside the matrix when there are no separators
 constexpr uint32_t kPadRow = 0u;                  // a row outside the model scores 0 for every symbol: it changes nothing and can never hit
+constexpr int kMaxRowCuts = 32;                   // row blocks of individual height in front of the uniform ones (SsvRare::row_cut)
 constexpr int kWindowSteps = 4;                   // steps between two hit tests where the model allows it (ssv_prepare_model)
 
 // per-wave LDS: 16 step-pair tables of 17 entries x 8 B, the record stage
@@ -348,16 +349,19 @@ struct SsvRare {
     const uint16_t* pair_mask;     // separator bitmap (boundary mode); the kernel is given safe_chunks == nullptr exactly when it is set
     uint32_t* tickets;             // the ticket counter of row-split launches
     uint32_t* block_flags;         // per tile of this launch: row blocks finished
-    uint32_t* block_state;         // per tile: 16 x 64 scores handed from one row block to the next
+    uint32_t* block_state;         // per tile: 8 x 64 words = the 2048 scores (a byte each) handed from one row block to the next
     uint32_t* fault;               // raised when a wait for a row block ran out (never expected)
     uint32_t row_bits;             // width of the row field of the sort key
-    // the tiling of this launch: read once per item (see "work distribution" below)
+    // the tiling of this launch and how it is handed out: read once per block / item (see "work distribution" below)
     int64_t first_diag; uint32_t tile_begin, ntiles;
     int64_t col_end;
-    uint32_t nitems;               // tiles, or tiles x row blocks, or groups of tiles_per_item tiles
-    uint32_t rows_per_block;       // 0: tiles are not split by rows (an item is a tile); else a multiple of 1024
-    uint32_t tiles_per_item;       // >= 1; > 1 only for short models (rows_per_block == 0): a wave walks that many ADJACENT tiles,
-                                   // and what it staged leaves with one atomic per block at the end of all of them
+    uint32_t parts_log2;           // the launch's units are dealt to 2^parts_log2 partitions: block i belongs to partition i mod 2^parts_log2
+    uint32_t part_begin[9];        // partition k owns units [part_begin[k], part_begin[k+1]): runs of about equal WORK (tiles at the matrix's ends are short)
+    uint32_t tiles_per_item;       // >= 1; a unit is a tile, or a group of tiles_per_item ADJACENT tiles (short models only, never with row cuts)
+    uint32_t split_units;          // of every partition's units the LAST split_units are cut by rows (0: no tile of this launch is cut)
+    uint32_t nrow_blocks;          // row blocks of a cut tile
+    uint32_t ncuts, uniform_rows;  // block b < ncuts is rows [row_cut[b], row_cut[b+1]); from block ncuts on the blocks are uniform_rows rows each
+    uint32_t row_cut[kMaxRowCuts + 1];
     // side buffer for what a block still has staged when it ends (see "block tails"); tails == nullptr: the atomic path
     uint64_t* tails; uint32_t* tail_counts;
     // per-cell trace (ssv_diag_kernel_traced only): one CellRecord per cell of rows [cell_row0, +cell_rows) x columns [cell_col0, +cell_cols)
@@ -888,18 +892,15 @@ __device__ __forceinline__ uint32_t word_selector(uint32_t a) { return 0x040c000
 
 // ---- work distribution ------------------------------------------------------------------------------------------------
 // An item is a tile (2048 diagonals) or ONE ROW BLOCK of a tile: one item per wave, four per block, the blocks handed
-// out by the hardware's block scheduler.  Tall tiles are cut into row blocks of 8192 rows: as whole tiles they balance
-// badly (C3 as stated: 5,130 tiles of 503,329 rows on 5,120 wave slots: a second, nearly empty round).  The wave that finishes
-// rows [b R, (b+1) R) of a tile leaves its 16 score registers in global memory and raises the tile's block count; the
-// wave with the next row block of that tile picks them up.  Items are numbered row-block-major and a block takes its
-// four item numbers from a ticket it draws when it starts, so the row block a wave waits for is held by a block that
-// has started, whatever order blocks are dispatched in: the wait always ends.
+// out by the hardware's block scheduler.  Whole tiles balance badly at the end of a launch when they are tall (C3 as
+// stated: 5,130 tiles of 503,329 rows -- not even one round of wave slots; C5: eight rounds of 4 ms tiles), so the tiles
+// that run LAST are cut by rows (the host decides which and where: havac_dev.hip, plan_row_cuts).  The wave that finishes
+// rows [b0, b1) of a cut tile leaves its 16 score registers in global memory and raises the tile's block count; the
+// wave with the next row block of that tile picks them up.  See "items" in ssv_diag_body for the order of the items and
+// why a wait for a row block always ends.
 constexpr int kTicketStride = 16;          // the ticket counter and the fault word sit in cache lines of their own
-constexpr int kTicketCounters = 1;
+constexpr int kTicketCounters = 8;         // one per partition of a launch (SsvRare::parts_log2 <= 3)
 constexpr int kBlocksPerCu = 4 * HAVAC_WAVES_PER_SIMD / kWavesPerBlock;   // 24 waves per CU = 6 waves per SIMD
-constexpr uint32_t kRowsPerBlock = 8192;   // rows of a row block (a multiple of 1024: the chunk-flag words); a hand-off
-                                           // moves 2 x 4 KB per 8192 x 2048 cells
-constexpr uint64_t kSplitBelowRounds = 64; // tall tiles are split by rows when there are fewer of them than this many rounds of wave slots
 constexpr uint32_t kHandoffSpins = 1u << 26;   // x ~1 us: a minute, far beyond any row block (dense-hit models take ~1 s each)
 
 // 6 waves per SIMD: 80 VGPRs = cur 16 + nxt 16 + 16 match words in flight + ~19 window addresses + 4 prepared symbol words + a
@@ -941,12 +942,11 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         *(lds_words_out_t)(uintptr_t)(table_base + my_pair * kPairStride + kOutsideCode) = u32x2{outside, outside};
     }
 
-    // ---- one item: rows [row_begin, row_end) of tile `tile_in_launch` ----------------------------------------------
-    auto run_item = [&](const uint32_t item) -> bool {        // false: stop (abort requested, or a hand-off never came)
+    // ---- one item: tile `tile_in_launch` of the launch, all of its rows or (cut != 0) its row block `block` ---------------
+    auto run_item = [&](const uint32_t tile_arg, const uint32_t block_arg, const uint32_t cut) -> bool {   // false: stop (abort requested, or a hand-off never came)
+        // (wave-uniform, but a division may have left them in vector registers)
+        const uint32_t tile_in_launch = __builtin_amdgcn_readfirstlane(tile_arg), block = __builtin_amdgcn_readfirstlane(block_arg);
         const rare_args_t launch = rare_args();
-        const uint32_t rows_per_block = launch->rows_per_block;
-        uint32_t tile_in_launch = item, block = 0;
-        if (rows_per_block) { const uint32_t ntiles = launch->ntiles; block = item / ntiles; tile_in_launch = item - block * ntiles; }
         const uint32_t tile = launch->tile_begin + tile_in_launch;
         const int64_t d0 = launch->first_diag + (int64_t)tile * kTileDiags;     // wave's first diagonal
         // steps whose cells of this tile can lie inside the matrix
@@ -959,17 +959,23 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         if (hi64 < 0) hi64 = 0;
         const uint32_t p_lo = __builtin_amdgcn_readfirstlane((uint32_t)lo64), p_hi = __builtin_amdgcn_readfirstlane((uint32_t)hi64);
         uint32_t p_begin = p_lo, p_end = p_hi;                          // this item's share of them
-        if (rows_per_block) {
-            const uint32_t b0 = block * rows_per_block;
+        if (cut) {
+            // the block's rows [b0, b1): from the table for the first blocks, uniform blocks behind them
+            const uint32_t ncuts = launch->ncuts, uniform_rows = launch->uniform_rows, last_cut = launch->row_cut[ncuts];
+            const uint32_t b0 = block < ncuts ? launch->row_cut[block] : last_cut + (block - ncuts) * uniform_rows;
+            const uint32_t b1 = block < ncuts ? launch->row_cut[block + 1] : last_cut + (block - ncuts + 1) * uniform_rows;
             if (p_begin < b0) p_begin = b0;
-            if (p_end > b0 + rows_per_block) p_end = b0 + rows_per_block;
+            if (p_end > b1) p_end = b1;
         }
         if (p_begin >= p_end) return true;
-        // an abort request stops every item that has not started yet (the load travels with the item's first loads):
-        // a run of short models, whose items never reach the 2048-row poll below, drains at once too
+        // An abort request stops every item that has not started yet: a run of short models, whose items never reach the
+        // 2048-row poll below, drains at once too.  The word is read past the caches -- a trip to memory -- so the load is
+        // ISSUED here and looked at behind the item's first loads (symbols, model rows), with which it travels: tested at
+        // once, it cost a one-chunk tile a memory latency of its own before anything else had started.
+        uint32_t abort_now = 0;
         {
             const uint32_t* const abort_flag = rare_args()->abort_flag;
-            if (abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
+            if (abort_flag) abort_now = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
 
         uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_window)
@@ -980,7 +986,7 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             const uint32_t* const abort_flag = rare->abort_flag;
             uint32_t* const block_flags = rare->block_flags;
             uint32_t* const fault = rare->fault;
-            const uint32_t* const tile_state = rare->block_state + (size_t)tile_in_launch * (kRegs * 64);
+            const uint32_t* const tile_state = rare->block_state + (size_t)tile_in_launch * (kRegs / 2 * 64);
             uint32_t spins = 0;
             while (__hip_atomic_load(block_flags + tile_in_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < block) {
                 __builtin_amdgcn_s_sleep(32);
@@ -998,8 +1004,13 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const uint32_t my_lane = fresh_lane();
+            // (between chunks every cell is a multiple of 256 -- no mark is pending -- so a cell travels as its high byte: 2 KB per hand-off)
 #pragma unroll
-            for (int i = 0; i < kRegs; i++) x[i] = tile_state[i * 64 + my_lane];
+            for (int i = 0; i < kRegs / 2; i++) {
+                const uint32_t packed = tile_state[i * 64 + my_lane];
+                x[2 * i] = __builtin_amdgcn_perm(0u, packed, 0x010c000cu);
+                x[2 * i + 1] = __builtin_amdgcn_perm(0u, packed, 0x030c020cu);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < kRegs; i++) x[i] = kScoreZero;
@@ -1051,13 +1062,14 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         LazySymbols z;
         LaneWords mine = read_lane_words(lane_words_address);
         fetch_symbols(p_begin, z, mine.lane8);
+        if (__builtin_amdgcn_readfirstlane(abort_now)) return false;       // (a scalar branch: every lane read the same word)
         expand_all(C, z, std::make_integer_sequence<int, 16>{});       // -> C[16..32): the first chunk's lower half after the slide
+        ModelRows next_rows = fetch_rows(p_begin, mine);
+        fetch_symbols(p_begin + 32, z, mine.lane8);
         // The global loads of a chunk (12 B of model rows and 8 B of symbols per lane) are issued at the END of the chunk
         // before it and consumed at its top: no register carries them across the windows, and the latency that is
         // exposed this way is covered by the other four waves of the SIMD (measured in round 1: 2.12 ms against 2.16 ms
         // with the loads issued a whole chunk ahead).
-        ModelRows next_rows = fetch_rows(p_begin, mine);
-        fetch_symbols(p_begin + 32, z, mine.lane8);
 
         bool go_on = true;                 // wave-uniform
         // one bit per chunk: may the chunk look for hits every four steps only (ssv_prepare_model)?  never with separators.
@@ -1095,10 +1107,10 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         } else if (p_end < p_hi) {
             // the tile goes on in the next row block: hand the scores over (release: the stores, then the count)
             const rare_args_t rare = rare_args();
-            uint32_t* const tile_state = rare->block_state + (size_t)tile_in_launch * (kRegs * 64);
+            uint32_t* const tile_state = rare->block_state + (size_t)tile_in_launch * (kRegs / 2 * 64);
             const uint32_t my_lane = fresh_lane();
 #pragma unroll
-            for (int i = 0; i < kRegs; i++) tile_state[i * 64 + my_lane] = x[i];
+            for (int i = 0; i < kRegs / 2; i++) tile_state[i * 64 + my_lane] = __builtin_amdgcn_perm(x[2 * i + 1], x[2 * i], 0x07050301u);   // the four high bytes
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             if (my_lane == 0) __hip_atomic_store(rare->block_flags + tile_in_launch, block + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1106,29 +1118,50 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
     };
 
     // ---- items --------------------------------------------------------------------------------------------------------
-    // One item per wave, four per block, the blocks handed out by the hardware's block scheduler.  Whole tiles: the item
-    // is the wave's index.  Row blocks: the BLOCK draws a ticket when it starts (one returning atomic per four items)
-    // and its waves take items 4 ticket .. 4 ticket + 3 -- the order of the items is then the order in which blocks
-    // really started, whatever order the hardware dispatched them in, and the row block a wave waits for (a smaller
-    // item number) is held by a block that has started.
-    uint32_t first_item = blockIdx.x * kWavesPerBlock;
-    const uint32_t split_rows = rare_args()->rows_per_block;
-    if (split_rows) {
-        __shared__ uint32_t block_ticket;
-        if (wave == 0 && fresh_lane() == 0) block_ticket = __hip_atomic_fetch_add(rare_args()->tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        first_item = __builtin_amdgcn_readfirstlane(block_ticket) * kWavesPerBlock;
-    }
-    const uint32_t item = first_item + wave;         // wave-uniform
-    // Short models (host: tiles_per_item > 1): a tile of one or two chunks is mostly prologue, and every block that found a
-    // hit ends with a returning atomic on the one counter word, which sustains ~90 of them per microsecond chip-wide --
-    // at 100 Mbp x 32 rows the blocks ask for more than that.  A wave therefore walks several adjacent tiles.
-    if (item < rare_args()->nitems) {
-        const uint32_t per_item = split_rows ? 1u : rare_args()->tiles_per_item;
-        for (uint32_t g = 0; g < per_item; g++) {
-            const uint32_t unit = split_rows ? item : item * per_item + g;      // a tile x row block, or a tile
-            if (!split_rows && unit >= rare_args()->ntiles) break;
-            if (!run_item(unit)) break;
+    // One item per wave, four per block, the blocks handed out by the hardware's block scheduler.  Block i belongs to
+    // partition i mod 8 -- blocks are dealt round-robin over the eight XCDs, so a partition's blocks share an L2 (observed
+    // placement, used for speed only: nothing below depends on it) -- and a partition owns a RUN of adjacent units (runs of
+    // equal work, not of equal length: the tiles at the matrix's two ends cover fewer rows): the
+    // waves that stream the same stretch of the sequence, 2048 columns apart, run on one XCD at about the same time, and a
+    // row block is handed over inside one L2.  A partition's items: its whole units first, then the row blocks of its last
+    // split_units units, row-block-major.  Launches without cut tiles: the block's number says which four items it takes.
+    // With cut tiles the BLOCK draws a ticket from its partition's counter when it starts (one returning atomic per four
+    // items): the order of a partition's items is then the order in which its blocks really started, whatever order the
+    // hardware dispatched them in, and the row block a wave waits for (a smaller item number of the same partition) is
+    // held by a block that has started.
+    {
+        const rare_args_t launch = rare_args();
+        const uint32_t parts_log2 = launch->parts_log2, split_units = launch->split_units;
+        const uint32_t part = blockIdx.x & ((1u << parts_log2) - 1u);
+        uint32_t ticket = blockIdx.x >> parts_log2;
+        if (split_units) {
+            __shared__ uint32_t block_ticket;
+            if (wave == 0 && fresh_lane() == 0)
+                block_ticket = __hip_atomic_fetch_add(launch->tickets + part * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            ticket = __builtin_amdgcn_readfirstlane(block_ticket);
+        }
+        const uint32_t u0 = launch->part_begin[part], u1 = launch->part_begin[part + 1u];
+        const uint32_t mine = u1 - u0;
+        const uint32_t cut_units = split_units < mine ? split_units : mine, whole_units = mine - cut_units;
+        const uint32_t item = ticket * kWavesPerBlock + wave;         // wave-uniform; within the partition
+        // (ONE call site of run_item: with two, hipcc stops inlining it -- and a called function cannot read the kernarg segment)
+        uint32_t first_tile = 0, walk = 0, block = 0, cut = 0;
+        if (item < whole_units) {
+            // Short models (host: tiles_per_item > 1, experiments only): a wave walks several ADJACENT tiles
+            const uint32_t per_item = launch->tiles_per_item;
+            first_tile = (u0 + item) * per_item;
+            walk = per_item;
+        } else if (item - whole_units < cut_units * launch->nrow_blocks) {
+            const uint32_t j = item - whole_units;
+            block = j / cut_units;
+            first_tile = u0 + whole_units + (j - block * cut_units);
+            walk = 1; cut = 1;
+        }
+        const uint32_t ntiles = launch->ntiles;
+        for (uint32_t g = 0; g < walk; g++) {
+            if (first_tile + g >= ntiles) break;
+            if (!run_item(first_tile + g, block, cut)) break;
         }
     }
 

@@ -107,7 +107,8 @@ class ShardedSsv:
     are valid until that slot is submitted again, and the caller's current stream has been made to wait for them."""
 
     def __init__(self, hit_capacity: int, device: torch.device, depth: int = 1, gather_when_alone: bool = False, tuning=None):
-        """tuning: optional (rows_per_block, tiles_per_item, block_tails, ordering) for SsvContext.set_tuning (experiments)"""
+        """tuning: optional (rows_per_block, tiles_per_item, block_tails, ordering[, parts_log2, split_rounds_x4, short_rows, guide])
+        for SsvContext.set_tuning / set_split_tuning (experiments)"""
         self.device = device
         # rehearsals on one GPU: run the collectives even in a one-rank group
         self.gather_when_alone = gather_when_alone and dist.is_initialized()
@@ -116,7 +117,9 @@ class ShardedSsv:
         self.slots = [_Slot(hit_capacity, device, depth > 1) for _ in range(max(1, depth))]
         if tuning:
             for slot in self.slots:
-                slot.ctx.set_tuning(*tuning)
+                slot.ctx.set_tuning(*tuning[:4])
+                if len(tuning) > 4:
+                    slot.ctx.set_split_tuning(*tuning[4:8])
         _low, high = torch.cuda.Stream.priority_range()
         self.kernel_stream = torch.cuda.Stream(device, priority=high) if depth > 1 else None
         self.in_flight = []               # slot indices, oldest first

@@ -82,6 +82,13 @@ class HavacHwClient:
     def setHitCapacity(self, max_hits: int):
         self._check(self._L.havac_dev_set_hit_capacity(self._h, int(max_hits)))
 
+    def setTuning(self, *values: int):
+        """experiment knobs (include/havac_dev.h: havac_dev_set_tuning): rows_per_block, tiles_per_item, block_tails, ordering,
+        parts_log2, split_rounds_x4, short_rows, guide; -1 or missing = the library's own rule"""
+        import ctypes
+        arr = (ctypes.c_int32 * len(values))(*[int(v) for v in values])
+        self._check(self._L.havac_dev_set_tuning(self._h, arr, len(values)))
+
     def writeSequence(self, compressedSequence):
         buf = np.ascontiguousarray(compressedSequence, dtype=np.uint8)
         self._check(self._L.havac_dev_write_sequence(self._h, buf.ctypes.data, buf.size))

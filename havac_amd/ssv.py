@@ -68,6 +68,10 @@ class SsvContext:
         """experiment knobs of the next passes (include/havac_dev.h: havac_ssv_set_tuning); -1 = the library's own rule"""
         self._check(self._L.havac_ssv_set_tuning(self._h, rows_per_block, tiles_per_item, block_tails, ordering))
 
+    def set_split_tuning(self, parts_log2: int = -1, split_rounds_x4: int = -1, short_rows: int = -1, guide: int = -1):
+        """the library's rule for tall tiles (include/havac_dev.h: havac_ssv_set_split_tuning); -1 = the default"""
+        self._check(self._L.havac_ssv_set_split_tuning(self._h, parts_log2, split_rounds_x4, short_rows, guide))
+
     def last_ordering(self):
         """-> (path, buckets, largest bucket) of the last finished pass: path 0 radix sort, 1 bucket ordering, 2 fallback"""
         path, nb, big = C.c_int(0), C.c_uint32(0), C.c_uint32(0)

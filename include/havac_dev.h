@@ -100,6 +100,10 @@ void havac_dev_destroy(havac_dev *dev);
 
 /* Change the hit-buffer capacity (records). */
 int havac_dev_set_hit_capacity(havac_dev *dev, uint64_t max_hits);
+/* Experiment knobs of the handle's runs: up to eight values, in the order of havac_ssv_set_tuning's and then
+ * havac_ssv_set_split_tuning's arguments (see there; missing values and -1 = the library's own rule).  Applies to every
+ * GPU of the handle.  No counterpart in the reference. */
+int havac_dev_set_tuning(havac_dev *dev, const int32_t *values, uint32_t count);
 
 /* HavacHwClient::writeSequence  host/HavacHwClient.cpp:78-110.
  * Borrowed host pointer, copied to HBM before return. */
@@ -278,12 +282,19 @@ int havac_ssv_finish_end(havac_ssv_ctx *ctx, uint64_t *hit_count_out);
 
 /* Experiment knobs of the next passes (tools/, tests/): how the launch hands out work and how the records are ordered.
  * Every value: -1 = the library's own rule (the default).
- *   rows_per_block  rows of a row block (a multiple of 1024); 0 = never cut tiles into row blocks
+ *   rows_per_block  > 0: EVERY tile is cut into uniform row blocks of that many rows (a multiple of 1024);
+ *                   0 = never cut tiles into row blocks
  *   tiles_per_item  adjacent tiles a wave walks (>= 1; short models)
  *   block_tails     0 = never, 1 = the default rule, 2 = whatever the height of an item
  *   ordering        0 = always the generic radix sort, 1 = the bucket ordering (the default)
  * No counterpart in the reference. */
 int havac_ssv_set_tuning(havac_ssv_ctx *ctx, int rows_per_block, int tiles_per_item, int block_tails, int ordering);
+/* More of the same: the library's own rule for tall tiles.  Every value: -1 = keep the default.
+ *   parts_log2       the launch's tiles are dealt to 2^parts_log2 partitions of adjacent tiles (0 ... 3; 3 = one per XCD)
+ *   split_rounds_x4  the tiles of the launch's last split_rounds_x4 / 4 rounds of wave slots are cut by rows (default 6)
+ *   short_rows       finest row block (a multiple of 1024; default 4096); models below twice that are never cut
+ *   guide            a row block takes 1 / guide of the rows that are left (2 ... 16; default 2) */
+int havac_ssv_set_split_tuning(havac_ssv_ctx *ctx, int parts_log2, int split_rounds_x4, int short_rows, int guide);
 /* How the last finished pass was ordered: *path = 0 radix sort, 1 bucket ordering, 2 bucket ordering given up for the
  * radix sort (a bucket too big for an LDS sort); the number of buckets and the largest one. */
 int havac_ssv_last_ordering(havac_ssv_ctx *ctx, int *path, uint32_t *nbuckets, uint32_t *largest_bucket);

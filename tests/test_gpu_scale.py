@@ -478,3 +478,64 @@ def test_a_rank_needs_only_its_window_of_the_database(torch_dev, oracle):
         ctx.enqueue(window.data_ptr(), ncols, d_phmm.data_ptr(), model.shape[0], hits.data_ptr(), hits.numel(), 3, world, 0, stream)
     ctx.set_sequence_window(0, 0)
     ctx.close()
+
+
+@pytest.mark.parametrize("split", [
+    dict(),                                                       # the library's own rule
+    dict(parts_log2=3, split_rounds_x4=1),                        # eight partitions, each with whole tiles first and cut tiles last
+    dict(parts_log2=0, split_rounds_x4=1, short_rows=1024),       # one partition, finer cuts
+    dict(parts_log2=3, split_rounds_x4=0),                        # partitions of whole tiles only
+    dict(parts_log2=2, split_rounds_x4=64, short_rows=2048, guide=3),   # every tile cut
+])
+def test_partitions_whole_tiles_first_cut_tiles_last(torch_dev, oracle, split):
+    """How a launch hands out its tiles (ssv_kernels.hip.h, "items"; havac_dev.hip, plan_row_cuts): partitions of adjacent
+    tiles, whole tiles first, the last tiles cut by rows with cuts that get finer towards the model's end.  Whatever the
+    split, the whole hit list equals the checker's."""
+    torch, dev = torch_dev
+    O = oracle
+    from havac_amd.ssv import SsvContext
+    model, cons = synth.dfam_like_model(8200, 77)
+    ncols = 330 * synth.SEGMENT                                   # 1,980 tiles + the model's: more than 8 x 192 cut tiles
+    sym = synth.random_symbols(ncols, 78)
+    synth.plant_homologs(sym, cons, ncols, every=150_000, length=300)
+    packed = synth.pack_2bit(sym)
+    want = whole_list(O, packed, model, cap=1 << 24)
+    ctx = SsvContext()
+    ctx.set_split_tuning(**split)
+    d_seq = torch.from_numpy(packed).to(dev)
+    d_phmm = torch.from_numpy(np.ascontiguousarray(model).reshape(-1)).to(dev)
+    capacity = 1 << 24
+    hits = torch.empty(capacity, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(2):                                            # twice: tickets, flags and hand-off buffers are reused
+        ctx.enqueue(d_seq.data_ptr(), packed.size * 4, d_phmm.data_ptr(), model.shape[0], hits.data_ptr(), capacity, 0, 1, 0, stream)
+        n = ctx.finish()
+        got = hits[:n].cpu().numpy().view(np.uint64)
+        assert got.size == want.size and np.array_equal(got, want)
+    ctx.close()
+
+
+def test_row_cut_table_overflows_into_uniform_blocks(torch_dev, oracle):
+    """A slow taper over a tall model needs more row blocks than the table of individual cuts holds (32): the rest are uniform
+    blocks of the finest height.  65,536 rows, 1/16 of the remaining rows per block, finest block 1024 rows: 37 blocks."""
+    torch, dev = torch_dev
+    O = oracle
+    from havac_amd.ssv import SsvContext
+    model, cons = synth.dfam_like_model(65_500, 91)
+    ncols = 10 * synth.SEGMENT
+    sym = synth.random_symbols(ncols, 92)
+    synth.plant_homologs(sym, cons, ncols, every=30_000, length=400)
+    packed = synth.pack_2bit(sym)
+    want = whole_list(O, packed, model, cap=1 << 24)
+    ctx = SsvContext()
+    ctx.set_split_tuning(parts_log2=3, split_rounds_x4=64, short_rows=1024, guide=16)
+    d_seq = torch.from_numpy(packed).to(dev)
+    d_phmm = torch.from_numpy(np.ascontiguousarray(model).reshape(-1)).to(dev)
+    capacity = 1 << 24
+    hits = torch.empty(capacity, dtype=torch.int64, device=dev)
+    ctx.enqueue(d_seq.data_ptr(), packed.size * 4, d_phmm.data_ptr(), model.shape[0], hits.data_ptr(), capacity, 0, 1, 0,
+                torch.cuda.current_stream(dev).cuda_stream)
+    n = ctx.finish()
+    got = hits[:n].cpu().numpy().view(np.uint64)
+    assert got.size == want.size and np.array_equal(got, want)
+    ctx.close()

@@ -1,5 +1,5 @@
 """Kernel time against model height (32-row chunks per tile) on 100 Mbp, with a model that cannot hit and with the
-Dfam-like one.   python tools/rows_probe.py [rows ...]"""
+Dfam-like one.   python tools/rows_probe.py [--tuning=a,b,...] [rows ...]     (tuning: ShardedSsv's, see bench.py --tuning)"""
 import os
 import sys
 
@@ -15,8 +15,12 @@ dev = torch.device("cuda", 0)
 ncols = 100_012_032
 packed = synth.random_packed(ncols, synth.SEED_SEQUENCE)
 d_seq = torch.from_numpy(packed).to(dev)
-eng = ShardedSsv(1 << 23, dev)
-heights = [int(a) for a in sys.argv[1:]] or [32, 64, 96, 128, 160, 192, 256, 384, 512, 1024]
+args = sys.argv[1:]
+tuning = None
+if args and args[0].startswith("--tuning="):
+    tuning = [int(v) for v in args.pop(0)[len("--tuning="):].split(",")]
+eng = ShardedSsv(1 << 23, dev, tuning=tuning)
+heights = [int(a) for a in args] or [32, 64, 96, 128, 160, 192, 256, 384, 512, 1024]
 for nrows in heights:
     out = []
     for kind in ("nohit", "dfam"):
