@@ -53,6 +53,16 @@ for case in range(cases):
         synth.plant_homologs(sym, cons, n, every=int(rng.integers(500, 20000)), length=min(nrows, int(rng.integers(20, 600))),
                              sub=float(rng.uniform(0, 0.3)), seed=int(rng.integers(1 << 30)))
     use_mask = rng.random() < 0.3
+    # how the launch hands out its tiles (havac_dev_set_tuning): the library's own rule half of the time, else a random one --
+    # partitions or none, how many of the last tiles are cut, finest block, taper; or uniform row blocks for every tile
+    tuning = [-1] * 8
+    pick = rng.random()
+    if pick < 0.35:
+        tuning[4:8] = [int(rng.choice([0, 1, 2, 3])), int(rng.choice([0, 1, 2, 6, 64])), int(rng.choice([1024, 2048, 4096])), int(rng.choice([2, 3, 4, 16]))]
+    elif pick < 0.5:
+        tuning[0] = int(rng.choice([1024, 2048, 4096, 8192]))
+        tuning[4] = int(rng.choice([0, 3]))
+    c.setTuning(*tuning)
     c.writeSequence(synth.pack_2bit(sym))
     pieces = [(0, n)]
     if use_mask:
@@ -85,7 +95,7 @@ for case in range(cases):
     hits_total += want.size
     if not ok:
         bad += 1
-        print(f"MISMATCH case {case}: nseg={nseg} nrows={nrows} kind={kind} mask={use_mask} got {got.size} want {want.size}", flush=True)
+        print(f"MISMATCH case {case}: nseg={nseg} nrows={nrows} kind={kind} mask={use_mask} tuning={tuning} got {got.size} want {want.size}", flush=True)
     if case % (5 if big else 25) == (4 if big else 24):
         print(f"{case + 1} cases, {bad} mismatches, {cells:.3g} cells, {hits_total} hits, {time.time() - t0:.0f} s", flush=True)
 c.close()
