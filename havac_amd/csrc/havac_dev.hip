@@ -95,10 +95,10 @@ void shard_window(uint64_t nsymbols, uint32_t nrows, uint64_t col_begin, uint64_
 
 // ---- partitions of a launch's units ----------------------------------------------------------------------------------------
 struct PartitionKey {
-    uint64_t nsymbols = 0; uint32_t nrows = 0; uint64_t col_begin = 0, col_end = 0; uint32_t tb = 0, te = 0, per_item = 0, parts_log2 = 0;
+    uint64_t nsymbols = 0; uint32_t nrows = 0; uint64_t col_begin = 0, col_end = 0; uint32_t tb = 0, te = 0, parts_log2 = 0;
     bool operator==(const PartitionKey& o) const {
         return nsymbols == o.nsymbols && nrows == o.nrows && col_begin == o.col_begin && col_end == o.col_end && tb == o.tb && te == o.te &&
-               per_item == o.per_item && parts_log2 == o.parts_log2;
+               parts_log2 == o.parts_log2;
     }
 };
 // rows of tile `tile` (of the whole tiling) that the kernel walks: ssv_diag_body's p_lo, p_hi
@@ -108,26 +108,21 @@ inline uint64_t tile_rows(const Tiling& t, uint32_t tile, int64_t col_end) {
     const int64_t hi = std::min<int64_t>(std::max<int64_t>(col_end - d0, 0), t.nrows_padded);
     return hi > lo ? (uint64_t)(hi - lo) : 0u;
 }
-// part_begin[0 .. nparts]: unit numbers; partition k = units [part_begin[k], part_begin[k+1]) holds about 1/nparts of the rows
-void plan_partitions(const Tiling& t, uint32_t tile_begin, uint32_t ntiles, int64_t col_end, uint32_t per_item, uint32_t nparts, uint32_t* part_begin) {
-    const uint32_t nunits = (ntiles + per_item - 1) / per_item;
+// part_begin[0 .. nparts]: tiles of the launch; partition k = tiles [part_begin[k], part_begin[k+1]) holds about 1/nparts of the rows
+void plan_partitions(const Tiling& t, uint32_t tile_begin, uint32_t ntiles, int64_t col_end, uint32_t nparts, uint32_t* part_begin) {
     // (+ a constant per tile: its prologue and the step behind its last chunk -- what short tiles mostly consist of)
-    auto unit_work = [&](uint32_t u) {
-        uint64_t w = 0;
-        for (uint32_t g = 0; g < per_item && u * per_item + g < ntiles; g++) w += tile_rows(t, tile_begin + u * per_item + g, col_end) + 16;
-        return w;
-    };
+    auto tile_work = [&](uint32_t i) { return tile_rows(t, tile_begin + i, col_end) + 16; };
     uint64_t total = 0;
-    for (uint32_t u = 0; u < nunits; u++) total += unit_work(u);
+    for (uint32_t i = 0; i < ntiles; i++) total += tile_work(i);
     part_begin[0] = 0;
     uint64_t seen = 0;
     uint32_t k = 1;
-    for (uint32_t u = 0; u < nunits && k < nparts; u++) {
-        seen += unit_work(u);
-        while (k < nparts && seen * nparts >= total * k) part_begin[k++] = u + 1;
+    for (uint32_t i = 0; i < ntiles && k < nparts; i++) {
+        seen += tile_work(i);
+        while (k < nparts && seen * nparts >= total * k) part_begin[k++] = i + 1;
     }
-    while (k <= nparts) part_begin[k++] = nunits;
-    part_begin[nparts] = nunits;
+    while (k <= nparts) part_begin[k++] = ntiles;
+    part_begin[nparts] = ntiles;
 }
 
 // ---- row cuts of tall tiles ---------------------------------------------------------------------------------------------
@@ -155,6 +150,99 @@ RowCuts plan_row_cuts(uint32_t nrows_padded, uint32_t short_rows, uint32_t guide
     r.uniform_rows = short_rows;
     r.nrow_blocks = r.ncuts + (at < nrows_padded ? (nrows_padded - at + short_rows - 1) / short_rows : 0u);
     return r;
+}
+
+// ---- the plan of a launch -----------------------------------------------------------------------------------------------------
+// Everything about HOW a launch hands out its tiles (ssv_kernels.hip.h, "items"), from the shape of the problem and the number
+// of wave slots alone -- no device is touched: havac_ssv_plan (tests, tools) and havac_ssv_enqueue call the same function.
+//  * eight partitions of adjacent tiles, one per XCD under the observed round-robin placement, of equal work;
+//  * whole tiles first; where tiles are tall, the LAST tiles of every partition -- the last split_rounds rounds of wave slots
+//    of the launch -- are cut by rows, the cuts getting finer towards the model's end (plan_row_cuts), so that the launch ends
+//    everywhere at about the same time.  Round 2 cut EVERY tile into blocks of 8192 rows: the same balance, but a hand-off per
+//    8192 x 2048 cells was 7-9 x the bytes the problem needs on C3 and C5.  (Cutting SHORT tiles to fill the last round -- C2
+//    is 9.54 rounds -- does not pay: 2, 3, 4 row blocks per 1024-row tile took 2.20, 3.22, 4.5 ms against 2.02.);
+struct PlanTuning { int rows_per_block, tiles_per_item, parts_log2; uint32_t split_rounds_x4, short_rows, guide; };
+struct LaunchPlan { SsvRare L{}; uint32_t nblocks = 0, largest_item_rows = 0; };
+int plan_launch(std::string& err, const Tiling& t, uint32_t tb, uint32_t te, int64_t col_end, uint64_t slots, const PlanTuning& tune,
+                const uint32_t* known_part_begin /* 9 entries of an earlier plan of the same shape, or null */, LaunchPlan& plan) {
+    SsvRare& L = plan.L;
+    L.first_diag = t.first_diag; L.tile_begin = tb; L.ntiles = te - tb;
+    L.col_end = col_end;
+    L.parts_log2 = L.ntiles >= 64 ? 3u : 0u;
+    if (tune.parts_log2 >= 0) L.parts_log2 = (uint32_t)tune.parts_log2;
+    const uint32_t nparts = 1u << L.parts_log2;
+    RowCuts cuts{};
+    uint32_t split_units = 0;
+    if (te > tb && tune.rows_per_block < 0 && t.nrows_padded >= 2 * tune.short_rows) {
+        split_units = (uint32_t)((tune.split_rounds_x4 * slots / 4 + nparts - 1) / nparts);
+        if ((uint64_t)split_units * nparts >= L.ntiles) {
+            // Fewer tiles than wave slots, or hardly more (C3 as stated: 5,130 tiles of 503,329 rows): every tile is a chain of row
+            // blocks that runs from the launch's start to its end, and what keeps the chains in step is that the waves which WAIT
+            // (there are more slots than chains) change places often.  Uniform blocks, then -- a taper that opens with half the rows
+            // leaves the same SIMDs overbooked for half the launch (measured on C3: 97.3 ms against 89.6) -- of about 1/16 of the
+            // model: blocks of 8192 rows (round 2) balance 0.5 % better than blocks of 16384 and move 1.5 x the bytes.
+            const uint32_t rows = std::min(std::max((t.nrows_padded / 16 + 1023u) / 1024u * 1024u, 2 * tune.short_rows), kChainRows);
+            cuts.ncuts = 0; cuts.cut[0] = 0; cuts.uniform_rows = rows;
+            cuts.nrow_blocks = (t.nrows_padded + rows - 1) / rows;
+            split_units = 0xffffffffu;
+        } else {
+            cuts = plan_row_cuts(t.nrows_padded, tune.short_rows, tune.guide);
+        }
+    } else if (te > tb && tune.rows_per_block > 0) {                       // experiments and tests (havac_ssv_set_tuning): uniform blocks, every tile cut
+        const uint32_t rows_per_block = (uint32_t)tune.rows_per_block / 1024u * 1024u;    // whole chunk-flag words
+        if (rows_per_block && rows_per_block < t.nrows_padded) {
+            split_units = 0xffffffffu;
+            cuts.ncuts = 0; cuts.cut[0] = 0; cuts.uniform_rows = rows_per_block;
+            cuts.nrow_blocks = (t.nrows_padded + rows_per_block - 1) / rows_per_block;
+        }
+    }
+    if (cuts.nrow_blocks < 2) split_units = 0;
+    const bool split = split_units != 0;
+    // Groups of adjacent tiles per wave (short models) are an experiment only: the waves of a round then walk in step, wait for
+    // memory together and hide nothing of each other's prologues -- 4 tiles per wave 4-6 % slower than single tiles, 8 tiles
+    // 10 %, with or without the next tile's symbols fetched a tile ahead.  tiles_per_item = G > 1: every tile in a
+    // group; G < -1: groups of -G tiles, but a partition's last round of wave slots as single tiles.
+    uint32_t tiles_per_item = 1, single_tiles = 0;
+    if (tune.tiles_per_item >= 1 && !split) tiles_per_item = (uint32_t)tune.tiles_per_item;
+    if (tune.tiles_per_item < -1 && !split) { tiles_per_item = (uint32_t)(-tune.tiles_per_item); single_tiles = (uint32_t)((slots + nparts - 1) / nparts); }
+    L.tiles_per_item = tiles_per_item; L.single_tiles = single_tiles;
+    plan.nblocks = 0;
+    plan.largest_item_rows = t.nrows_padded;
+    if (te <= tb) return HAVAC_OK;
+    L.split_units = split_units;
+    L.nrow_blocks = split ? cuts.nrow_blocks : 1u;
+    L.ncuts = cuts.ncuts; L.uniform_rows = cuts.uniform_rows;
+    for (uint32_t i = 0; i <= (uint32_t)kMaxRowCuts; i++) L.row_cut[i] = cuts.cut[i];
+    // partitions: runs of tiles of about equal work (a tile's work = its rows inside the matrix and the shard's columns: the
+    // tiles at the matrix's two ends are triangles -- with C3's 503,329 rows the first and the last eighth of the tiles would
+    // hold 19 % less work than the others)
+    if (known_part_begin) {
+        for (uint32_t k = 0; k <= 8; k++) L.part_begin[k] = known_part_begin[k];
+    } else {
+        uint32_t begin[9];
+        plan_partitions(t, tb, te - tb, col_end, nparts, begin);
+        for (uint32_t k = 0; k <= 8; k++) L.part_begin[k] = begin[std::min(k, nparts)];
+    }
+    // blocks: every partition gets as many as its largest sibling needs (a block without items leaves at once)
+    uint64_t most_items = 0;
+    bool any_whole = false;
+    for (uint32_t k = 0; k < nparts; k++) {
+        const uint64_t mine = L.part_begin[k + 1] - L.part_begin[k], cut_units = std::min<uint64_t>(split_units, mine), whole = mine - cut_units;
+        const uint64_t groups = tiles_per_item > 1 ? (whole - std::min<uint64_t>(single_tiles, whole)) / tiles_per_item : 0;
+        most_items = std::max(most_items, groups + (whole - groups * tiles_per_item) + cut_units * L.nrow_blocks);
+        any_whole = any_whole || whole > 0;
+    }
+    const uint64_t blocks64 = (most_items + kWavesPerBlock - 1) / kWavesPerBlock * nparts;
+    if (blocks64 * (64 * kWavesPerBlock) >= (1ull << 32)) {      // a dispatch counts its work-items in 32 bits
+        err = "too many tiles x row blocks for one launch (" + std::to_string(blocks64) + " workgroups)";
+        return HAVAC_E_LENGTH;
+    }
+    plan.nblocks = (uint32_t)blocks64;
+    if (split && !any_whole) {
+        plan.largest_item_rows = cuts.uniform_rows;
+        for (uint32_t i = 0; i < cuts.ncuts; i++) plan.largest_item_rows = std::max(plan.largest_item_rows, cuts.cut[i + 1] - cuts.cut[i]);
+    }
+    return HAVAC_OK;
 }
 
 }  // namespace
@@ -197,6 +285,7 @@ struct havac_ssv_ctx {
     int tune_rows_per_block = -1, tune_tiles_per_item = -1, tune_block_tails = -1;
     // havac_ssv_set_split_tuning: partitions (-1: the library decides), rounds of wave slots whose tiles are cut (x4), finest row block, taper
     PartitionKey part_key{}; uint32_t part_begin[9] = {};            // the partitions of the last launch's shape (plan_partitions)
+    uint32_t last_plan_blocks = 0, last_plan_item_rows = 0;
     int tune_parts_log2 = -1; uint32_t tune_split_rounds_x4 = kSplitRoundsX4, tune_short_rows = kShortRows, tune_guide = kCutGuide;
     // the pass enqueue() started and finish() completes
     bool pending = false, ordering = false;    // enqueue() done; finish_begin() done
@@ -343,6 +432,37 @@ extern "C" int havac_ssv_set_split_tuning(havac_ssv_ctx* c, int parts_log2, int 
     return HAVAC_OK;
 }
 
+static int check_inputs(std::string& err, uint64_t nsymbols, uint32_t nrows);
+extern "C" int havac_ssv_plan(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index, uint32_t shard_count, uint32_t wave_slots,
+                              const int32_t* tuning, uint32_t ntuning, havac_launch_plan* out) {
+    static_assert(kMaxRowCuts + 1 == 33, "havac_launch_plan::row_cut");
+    if (!out || shard_count == 0 || shard_index >= shard_count || (!tuning && ntuning)) return HAVAC_E_ARGUMENT;
+    std::string err;
+    if (int rc = check_inputs(err, nsymbols, nrows)) return rc;
+    int v[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    for (uint32_t i = 0; i < ntuning && i < 8; i++) v[i] = tuning[i];
+    if ((v[0] > 0 && v[0] < 1024) || v[4] > 3 || (v[6] >= 0 && v[6] < 1024) || v[7] == 0 || v[7] == 1 || v[7] > 16) return HAVAC_E_ARGUMENT;
+    const PlanTuning tune{v[0], v[1], v[4] < 0 ? -1 : v[4], v[5] < 0 ? kSplitRoundsX4 : (uint32_t)v[5],
+                          v[6] < 0 ? kShortRows : (uint32_t)v[6] / 1024u * 1024u, v[7] < 0 ? kCutGuide : (uint32_t)v[7]};
+    const Tiling t = make_tiling(nsymbols, nrows);
+    uint64_t col_begin, col_end;
+    shard_columns(nsymbols, shard_index, shard_count, &col_begin, &col_end);
+    uint32_t tb, te;
+    shard_tiles(t, nrows, col_begin, col_end, &tb, &te);
+    LaunchPlan plan;
+    if (int rc = plan_launch(err, t, tb, te, (int64_t)col_end, wave_slots ? wave_slots : 256u * kBlocksPerCu * kWavesPerBlock, tune, nullptr, plan)) return rc;
+    const SsvRare& L = plan.L;
+    std::memset(out, 0, sizeof(*out));
+    out->nrows_padded = t.nrows_padded; out->tile_begin = L.tile_begin; out->ntiles = L.ntiles;
+    out->nparts = 1u << L.parts_log2;
+    for (uint32_t k = 0; k <= 8; k++) out->part_begin[k] = L.part_begin[k];
+    out->tiles_per_group = L.tiles_per_item; out->single_tiles = L.single_tiles; out->cut_tiles = L.split_units;
+    out->nrow_blocks = L.ntiles ? L.nrow_blocks : 0; out->ncuts = L.ncuts; out->uniform_rows = L.uniform_rows;
+    for (uint32_t i = 0; i <= (uint32_t)kMaxRowCuts; i++) out->row_cut[i] = L.row_cut[i];
+    out->workgroups = plan.nblocks;
+    return HAVAC_OK;
+}
+
 extern "C" int havac_ssv_last_ordering(havac_ssv_ctx* c, int* path, uint32_t* nbuckets, uint32_t* largest_bucket) {
     if (!c) return HAVAC_E_ARGUMENT;
     if (path) *path = c->last_order_path;
@@ -439,91 +559,24 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     unsigned row_bits = 1, seg_bits = 1;
     while ((1u << row_bits) < t.nrows_padded + 2u) row_bits++;
     while ((1ull << seg_bits) < nsymbols / HAVAC_SEGMENT_COLUMNS) seg_bits++;
-    // ---- how the tiles are handed out (ssv_kernels.hip.h, "work distribution") ----
+    // ---- how the tiles are handed out (plan_launch; ssv_kernels.hip.h, "items") ----
     SsvRare L{};          // the kernel's first argument: tiling, hit queue, hand-off buffers (read from the kernarg segment on demand)
-    L.first_diag = t.first_diag; L.tile_begin = tb; L.ntiles = te - tb;
-    L.col_end = (int64_t)col_end;
-    // How the tiles are handed out (ssv_kernels.hip.h, "items"): eight partitions of adjacent tiles, one per XCD under the
-    // observed round-robin placement; whole tiles first; where tiles are tall, the LAST tiles of every partition -- the last
-    // kSplitRounds rounds of wave slots of the launch -- are cut by rows, the cuts getting finer towards the model's end
-    // (plan_row_cuts), so that the launch ends everywhere at about the same time.  Round 2 cut EVERY tile into blocks of 8192
-    // rows: the same balance, but a hand-off (2 x 4 KB through memory) per 8192 x 2048 cells was 7-9 x the bytes the problem needs on
-    // C3 and C5.  (Cutting SHORT tiles to fill the last round -- C2 is 9.54 rounds -- does not pay: 2, 3, 4 row blocks per
-    // 1024-row tile took 2.20, 3.22, 4.5 ms against 2.02.)
     const uint64_t slots = (uint64_t)c->resident_blocks * kWavesPerBlock;
-    L.parts_log2 = L.ntiles >= 64 ? 3u : 0u;
-    if (c->tune_parts_log2 >= 0) L.parts_log2 = (uint32_t)c->tune_parts_log2;
-    const uint32_t nparts = 1u << L.parts_log2;
-    RowCuts cuts{};
-    uint32_t split_units = 0;
-    if (te > tb && c->tune_rows_per_block < 0 && t.nrows_padded >= 2 * c->tune_short_rows) {
-        split_units = (uint32_t)((c->tune_split_rounds_x4 * slots / 4 + nparts - 1) / nparts);
-        if ((uint64_t)split_units * nparts >= L.ntiles) {
-            // Fewer tiles than wave slots, or hardly more (C3 as stated: 5,130 tiles of 503,329 rows): every tile is a chain of row
-            // blocks that runs from the launch's start to its end, and what keeps the chains in step is that the waves which WAIT
-            // (there are more slots than chains) change places often.  Uniform blocks, then -- a taper that opens with half the rows
-            // leaves the same SIMDs overbooked for half the launch (measured on C3: 97.3 ms against 89.6) -- of about 1/16 of the
-            // model: blocks of 8192 rows (round 2) balance 1.3 % better than blocks of 32768 and move 2.4 x the bytes.
-            const uint32_t rows = std::min(std::max((t.nrows_padded / 16 + 1023u) / 1024u * 1024u, 2 * c->tune_short_rows), kChainRows);
-            cuts.ncuts = 0; cuts.cut[0] = 0; cuts.uniform_rows = rows;
-            cuts.nrow_blocks = (t.nrows_padded + rows - 1) / rows;
-            split_units = 0xffffffffu;
-        } else {
-            cuts = plan_row_cuts(t.nrows_padded, c->tune_short_rows, c->tune_guide);
-        }
-    } else if (te > tb && c->tune_rows_per_block > 0) {                       // experiments and tests (havac_ssv_set_tuning): uniform blocks, every tile cut
-        const uint32_t rows_per_block = (uint32_t)c->tune_rows_per_block / 1024u * 1024u;    // whole chunk-flag words
-        if (rows_per_block && rows_per_block < t.nrows_padded) {
-            split_units = 0xffffffffu;
-            cuts.ncuts = 0; cuts.cut[0] = 0; cuts.uniform_rows = rows_per_block;
-            cuts.nrow_blocks = (t.nrows_padded + rows_per_block - 1) / rows_per_block;
-        }
+    const PlanTuning tuning{c->tune_rows_per_block, c->tune_tiles_per_item, c->tune_parts_log2, c->tune_split_rounds_x4, c->tune_short_rows, c->tune_guide};
+    {
+        // (the partitions are kept from pass to pass while the shape stays the same: a pass of C2 is 1.9 ms, the table takes 50,000 tiles)
+        const PartitionKey key{nsymbols, nrows, col_begin, col_end, tb, te, (uint32_t)c->tune_parts_log2};
+        const bool cached = key == c->part_key;
+        LaunchPlan plan;
+        if (int prc = plan_launch(c->err, t, tb, te, (int64_t)col_end, slots, tuning, cached ? c->part_begin : nullptr, plan)) return prc;
+        if (!cached) { for (uint32_t k = 0; k <= 8; k++) c->part_begin[k] = plan.L.part_begin[k]; c->part_key = key; }
+        L = plan.L;
+        c->last_plan_blocks = plan.nblocks; c->last_plan_item_rows = plan.largest_item_rows;
     }
-    if (cuts.nrow_blocks < 2) split_units = 0;
-    const bool split = split_units != 0;
-    // A wave can walk several adjacent tiles (ssv_kernels.hip.h, "items"; havac_ssv_set_tuning).  Built for short models, whose
-    // blocks queued up at the hit counter; the block tails removed that queue altogether, and with them groups of two
-    // tiles are 1-3 % SLOWER than single tiles (fewer, longer items balance worse): off unless forced.
-    uint32_t tiles_per_item = 1;
-    if (c->tune_tiles_per_item >= 1 && !split) tiles_per_item = (uint32_t)c->tune_tiles_per_item;      // experiments
-    L.tiles_per_item = tiles_per_item;
-    uint32_t nblocks = 0;
-    uint32_t largest_item_rows = t.nrows_padded;
+    const uint32_t nblocks = c->last_plan_blocks, largest_item_rows = c->last_plan_item_rows;
+    const bool split = L.split_units != 0;
     if (te > tb) {
-        L.split_units = split_units;
-        L.nrow_blocks = split ? cuts.nrow_blocks : 1u;
-        L.ncuts = cuts.ncuts; L.uniform_rows = cuts.uniform_rows;
-        for (uint32_t i = 0; i <= kMaxRowCuts; i++) L.row_cut[i] = cuts.cut[i];
-        // partitions: runs of units of about equal work (a tile's work = its rows inside the matrix and the shard's columns: the
-        // tiles at the matrix's two ends are triangles -- with C3's 503,329 rows the first and the last eighth of the tiles would
-        // hold 19 % less work than the others); kept from pass to pass while the shape stays the same
-        {
-            const PartitionKey key{nsymbols, nrows, col_begin, col_end, tb, te, tiles_per_item, L.parts_log2};
-            if (!(key == c->part_key)) {
-                plan_partitions(t, tb, te - tb, (int64_t)col_end, tiles_per_item, nparts, c->part_begin);
-                c->part_key = key;
-            }
-            for (uint32_t k = 0; k <= 8; k++) L.part_begin[k] = c->part_begin[std::min(k, nparts)];
-        }
-        // blocks: every partition gets as many as its largest sibling needs (a block without items leaves at once)
-        uint64_t most_items = 0;
-        bool any_whole = false;
-        for (uint32_t k = 0; k < nparts; k++) {
-            const uint64_t mine = L.part_begin[k + 1] - L.part_begin[k], cut_units = std::min<uint64_t>(split_units, mine);
-            most_items = std::max(most_items, (mine - cut_units) + cut_units * L.nrow_blocks);
-            any_whole = any_whole || mine > cut_units;
-        }
-        const uint64_t blocks64 = (most_items + kWavesPerBlock - 1) / kWavesPerBlock * nparts;
-        if (blocks64 * (64 * kWavesPerBlock) >= (1ull << 32)) {      // a dispatch counts its work-items in 32 bits
-            c->err = "too many tiles x row blocks for one launch (" + std::to_string(blocks64) + " workgroups)";
-            return HAVAC_E_LENGTH;
-        }
-        nblocks = (uint32_t)blocks64;
         if (split) {
-            if (!any_whole) {
-                largest_item_rows = cuts.uniform_rows;
-                for (uint32_t i = 0; i < cuts.ncuts; i++) largest_item_rows = std::max(largest_item_rows, cuts.cut[i + 1] - cuts.cut[i]);
-            }
             if (c->block_flag_tiles < L.ntiles) {
                 HIP_TRY(c->err, hipStreamSynchronize(stream));        // an earlier pass on this stream may still use the old buffers
                 if (c->block_flags) (void)hipFree(c->block_flags);

@@ -356,8 +356,9 @@ struct SsvRare {
     int64_t first_diag; uint32_t tile_begin, ntiles;
     int64_t col_end;
     uint32_t parts_log2;           // the launch's units are dealt to 2^parts_log2 partitions: block i belongs to partition i mod 2^parts_log2
-    uint32_t part_begin[9];        // partition k owns units [part_begin[k], part_begin[k+1]): runs of about equal WORK (tiles at the matrix's ends are short)
-    uint32_t tiles_per_item;       // >= 1; a unit is a tile, or a group of tiles_per_item ADJACENT tiles (short models only, never with row cuts)
+    uint32_t part_begin[9];        // partition k owns tiles [part_begin[k], part_begin[k+1]) of the launch: runs of about equal WORK (tiles at the matrix's ends are short)
+    uint32_t tiles_per_item;       // >= 1; > 1 (experiments, short models): a wave walks a GROUP of that many adjacent tiles
+    uint32_t single_tiles;         // ... except a partition's last single_tiles whole tiles, which are items of their own (the launch's last round)
     uint32_t split_units;          // of every partition's units the LAST split_units are cut by rows (0: no tile of this launch is cut)
     uint32_t nrow_blocks;          // row blocks of a cut tile
     uint32_t ncuts, uniform_rows;  // block b < ncuts is rows [row_cut[b], row_cut[b+1]); from block ncuts on the blocks are uniform_rows rows each
@@ -898,6 +899,7 @@ __device__ __forceinline__ uint32_t word_selector(uint32_t a) { return 0x040c000
 // rows [b0, b1) of a cut tile leaves its 16 score registers in global memory and raises the tile's block count; the
 // wave with the next row block of that tile picks them up.  See "items" in ssv_diag_body for the order of the items and
 // why a wait for a row block always ends.
+constexpr uint32_t kWholeTile = 0xffffffffu;  // run_item: not a row block, the whole tile
 constexpr int kTicketStride = 16;          // the ticket counter and the fault word sit in cache lines of their own
 constexpr int kTicketCounters = 8;         // one per partition of a launch (SsvRare::parts_log2 <= 3)
 constexpr int kBlocksPerCu = 4 * HAVAC_WAVES_PER_SIMD / kWavesPerBlock;   // 24 waves per CU = 6 waves per SIMD
@@ -943,9 +945,10 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
     }
 
     // ---- one item: tile `tile_in_launch` of the launch, all of its rows or (cut != 0) its row block `block` ---------------
-    auto run_item = [&](const uint32_t tile_arg, const uint32_t block_arg, const uint32_t cut) -> bool {   // false: stop (abort requested, or a hand-off never came)
+    auto run_item = [&](const uint32_t tile_arg, const uint32_t block_arg /* kWholeTile: all rows */) -> bool {   // false: stop (abort requested, or a hand-off never came)
         // (wave-uniform, but a division may have left them in vector registers)
         const uint32_t tile_in_launch = __builtin_amdgcn_readfirstlane(tile_arg), block = __builtin_amdgcn_readfirstlane(block_arg);
+        const uint32_t cut = block != kWholeTile ? 1u : 0u;
         const rare_args_t launch = rare_args();
         const uint32_t tile = launch->tile_begin + tile_in_launch;
         const int64_t d0 = launch->first_diag + (int64_t)tile * kTileDiags;     // wave's first diagonal
@@ -1022,28 +1025,45 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         uint32_t C[32];
         // The 32 symbols (8 bytes) of this lane at position d0 + rel + 32 lane, rel wave-uniform, ready for expansion;
         // the wave's 512 bytes are consecutive: a uniform base and the lane's byte offset.
-        auto fetch_symbols = [&](int64_t rel, LazySymbols& z, const uint32_t lane8) {
-            const int64_t first = d0 + rel;                               // the wave's first position
+        // In three parts (the scalars and the loaded words travel separately: in one struct, the lane-dependent branch around the
+        // loads made hipcc treat the scalars as per-lane values too.)
+        struct SymbolRange { int64_t first; int32_t valid_lo, valid_hi; uint32_t edge; };
+        auto symbol_range = [&](int64_t rel) -> SymbolRange {
+            SymbolRange e;
+            e.first = d0 + rel;                                           // the wave's first position
             // positions relative to `first` that lie inside [0, N), clamped to [0, 4096]: all of it on the scalar unit
-            z.valid_lo = clamp_to_4096(-first);
-            z.valid_hi = clamp_to_4096(nsymbols - first);
-            const uint32_t edge = (uint32_t)(z.valid_lo != 0) | (uint32_t)(z.valid_hi < kTileDiags);   // first < 0, or first + 2048 > N
-            const uint8_t* const base = seq + (first >> 2);             // only dereferenced for lanes inside [0, N)
-            z.table_base = table_base;
-            uint2 w = make_uint2(0u, 0u);
-            z.separators = 0;
-            if (!edge) {                                                  // the usual case: one coalesced load, uniform base + lane offset
+            e.valid_lo = clamp_to_4096(-e.first);
+            e.valid_hi = clamp_to_4096(nsymbols - e.first);
+            e.edge = (uint32_t)(e.valid_lo != 0) | (uint32_t)(e.valid_hi < kTileDiags);   // first < 0, or first + 2048 > N
+            return e;
+        };
+        auto load_symbols = [&](const SymbolRange& e, const uint32_t lane8, uint2& w, uint32_t& separators) {
+            const uint8_t* const base = seq + (e.first >> 2);           // only dereferenced for lanes inside [0, N)
+            w = make_uint2(0u, 0u);
+            separators = 0;
+            if (!e.edge) {                                                // the usual case: one coalesced load, uniform base + lane offset
                 // (lane8 comes fresh from LDS in this block: its zero-extension folds into the load's "SGPR base + 32-bit VGPR offset" form)
                 w = *reinterpret_cast<const uint2*>(base + lane8);
-                if (fresh_uniform(has_mask)) z.separators = rare_args()->pair_mask[(first >> 5) + (lane8 >> 3)];
-            } else if ((int32_t)(lane8 * 4) >= z.valid_lo && (int32_t)(lane8 * 4) + 32 <= z.valid_hi) {
+                if (fresh_uniform(has_mask)) separators = rare_args()->pair_mask[(e.first >> 5) + (lane8 >> 3)];
+            } else if ((int32_t)(lane8 * 4) >= e.valid_lo && (int32_t)(lane8 * 4) + 32 <= e.valid_hi) {
                 w = *reinterpret_cast<const uint2*>(base + lane8);
-                if (fresh_uniform(has_mask)) z.separators = rare_args()->pair_mask[(first >> 5) + (lane8 >> 3)];
+                if (fresh_uniform(has_mask)) separators = rare_args()->pair_mask[(e.first >> 5) + (lane8 >> 3)];
             }
-            uint32_t special = edge;                                      // from scalars and a ballot only: stays on the scalar unit
+        };
+        auto finish_symbols = [&](const SymbolRange& e, const uint2 w, const uint32_t separators, LazySymbols& z) {
+            z.valid_lo = e.valid_lo; z.valid_hi = e.valid_hi;
+            z.table_base = table_base;
+            z.separators = separators;
+            uint32_t special = e.edge;                                    // from scalars and a ballot only: stays on the scalar unit
             if (fresh_uniform(has_mask)) special |= __any(z.separators != 0) ? 1u : 0u;
             z.special = opaque_uniform(special);
             prepare_symbols(z, w.x, w.y);
+        };
+        auto fetch_symbols = [&](int64_t rel, LazySymbols& z, const uint32_t lane8) {
+            const SymbolRange e = symbol_range(rel);
+            uint2 w; uint32_t separators;
+            load_symbols(e, lane8, w, separators);
+            finish_symbols(e, w, separators, z);
         };
         // A chunk's 16 step-pair tables: entry (a,b) of pair P = { word(step 2P, a), word(step 2P+1, b) } with
         // word(t, a) = (M[t][a] << 8) | (M[t-1][a] << 24); rows[] is shifted by one, so rows[t] is M[t-1].
@@ -1141,27 +1161,34 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             __syncthreads();
             ticket = __builtin_amdgcn_readfirstlane(block_ticket);
         }
-        const uint32_t u0 = launch->part_begin[part], u1 = launch->part_begin[part + 1u];
-        const uint32_t mine = u1 - u0;
-        const uint32_t cut_units = split_units < mine ? split_units : mine, whole_units = mine - cut_units;
         const uint32_t item = ticket * kWavesPerBlock + wave;         // wave-uniform; within the partition
-        // (ONE call site of run_item: with two, hipcc stops inlining it -- and a called function cannot read the kernarg segment)
-        uint32_t first_tile = 0, walk = 0, block = 0, cut = 0;
-        if (item < whole_units) {
-            // Short models (host: tiles_per_item > 1, experiments only): a wave walks several ADJACENT tiles
-            const uint32_t per_item = launch->tiles_per_item;
-            first_tile = (u0 + item) * per_item;
-            walk = per_item;
-        } else if (item - whole_units < cut_units * launch->nrow_blocks) {
-            const uint32_t j = item - whole_units;
-            block = j / cut_units;
-            first_tile = u0 + whole_units + (j - block * cut_units);
-            walk = 1; cut = 1;
-        }
-        const uint32_t ntiles = launch->ntiles;
-        for (uint32_t g = 0; g < walk; g++) {
-            if (first_tile + g >= ntiles) break;
-            if (!run_item(first_tile + g, block, cut)) break;
+        // A partition's tiles [t0, t1), in the order its items take them: groups of tiles_per_item adjacent tiles (a wave WALKS a
+        // group; experiments on short models only), single tiles, then the row blocks of its last split_units tiles,
+        // row-block-major.  (Decoded afresh for every tile of a walk -- a dozen scalar instructions: only `item` and the count
+        // stay alive across a tile, and the hot loop is as short of scalar registers as of vector ones.  ONE call site of run_item:
+        // with two, hipcc stops inlining it -- and a called function cannot read the kernarg segment.)
+        for (uint32_t g = 0;; g++) {
+            const rare_args_t plan = rare_args();
+            const uint32_t t0 = plan->part_begin[part], t1 = plan->part_begin[part + 1u];
+            const uint32_t mine = t1 - t0, cut_limit = plan->split_units;
+            const uint32_t cut_units = cut_limit < mine ? cut_limit : mine, whole = mine - cut_units;
+            const uint32_t per_group = plan->tiles_per_item, single_tiles = plan->single_tiles;
+            const uint32_t groups = per_group > 1 ? (whole - (single_tiles < whole ? single_tiles : whole)) / per_group : 0u;
+            const uint32_t singles = whole - groups * per_group;
+            uint32_t first_tile = 0, walk = 0, block = kWholeTile;
+            if (item < groups) {
+                first_tile = t0 + item * per_group;
+                walk = per_group;
+            } else if (item - groups < singles) {
+                first_tile = t0 + groups * per_group + (item - groups);
+                walk = 1;
+            } else if (item - groups - singles < cut_units * plan->nrow_blocks) {
+                const uint32_t j = item - groups - singles;
+                block = j / cut_units;
+                first_tile = t0 + whole + (j - block * cut_units);
+                walk = 1;
+            }
+            if (g >= walk || !run_item(first_tile + g, block)) break;
         }
     }
 

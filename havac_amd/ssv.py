@@ -108,3 +108,45 @@ def shard_window(nsymbols: int, nrows: int, shard_index: int, shard_count: int):
     if rc != 0:
         raise_for(rc, "bad shard arguments")
     return b.value, e.value
+
+
+class _LaunchPlan(C.Structure):
+    _fields_ = [("nrows_padded", C.c_uint32), ("tile_begin", C.c_uint32), ("ntiles", C.c_uint32),
+                ("nparts", C.c_uint32), ("part_begin", C.c_uint32 * 9),
+                ("tiles_per_group", C.c_uint32), ("single_tiles", C.c_uint32), ("cut_tiles", C.c_uint32),
+                ("nrow_blocks", C.c_uint32), ("ncuts", C.c_uint32), ("uniform_rows", C.c_uint32), ("row_cut", C.c_uint32 * 33),
+                ("workgroups", C.c_uint32)]
+
+
+def launch_plan(nsymbols: int, nrows: int, shard_index: int = 0, shard_count: int = 1, wave_slots: int = 0, tuning=()):
+    """How a launch of this shape hands out its tiles (include/havac_dev.h: havac_ssv_plan; no device needed) -> dict with
+    the partitions, the grouping of short models' tiles, the row blocks of cut tiles, and `items`: per partition the list of
+    (first tile of the launch, tiles walked, row block or None) in the order its workgroups take them."""
+    plan = _LaunchPlan()
+    arr = (C.c_int32 * max(1, len(tuning)))(*[int(v) for v in tuning])
+    rc = _lib.load().havac_ssv_plan(nsymbols, nrows, shard_index, shard_count, wave_slots, arr, len(tuning), C.byref(plan))
+    if rc != 0:
+        raise_for(rc, "no plan for this shape / tuning")
+    out = {name: getattr(plan, name) for name, _ in _LaunchPlan._fields_ if name not in ("part_begin", "row_cut")}
+    out["part_begin"] = list(plan.part_begin)[: plan.nparts + 1]
+    cuts = list(plan.row_cut)[: plan.ncuts + 1]
+    blocks = [(cuts[b], cuts[b + 1]) for b in range(plan.ncuts)]
+    at = cuts[-1] if cuts else 0
+    while len(blocks) < plan.nrow_blocks:
+        blocks.append((at, min(at + plan.uniform_rows, plan.nrows_padded)))
+        at += plan.uniform_rows
+    out["row_blocks"] = blocks if plan.nrow_blocks > 1 else []
+    items = []
+    for k in range(plan.nparts):
+        t0, t1 = plan.part_begin[k], plan.part_begin[k + 1]
+        mine = t1 - t0
+        cut = min(plan.cut_tiles, mine) if plan.nrow_blocks > 1 else 0
+        whole = mine - cut
+        g = plan.tiles_per_group
+        groups = (whole - min(plan.single_tiles, whole)) // g if g > 1 else 0
+        part = [(t0 + i * g, g, None) for i in range(groups)]
+        part += [(t, 1, None) for t in range(t0 + groups * g, t0 + whole)]
+        part += [(t0 + whole + j, 1, b) for b in range(plan.nrow_blocks if cut else 0) for j in range(cut)]
+        items.append(part)
+    out["items"] = items
+    return out

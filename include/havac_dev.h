@@ -284,7 +284,8 @@ int havac_ssv_finish_end(havac_ssv_ctx *ctx, uint64_t *hit_count_out);
  * Every value: -1 = the library's own rule (the default).
  *   rows_per_block  > 0: EVERY tile is cut into uniform row blocks of that many rows (a multiple of 1024);
  *                   0 = never cut tiles into row blocks
- *   tiles_per_item  adjacent tiles a wave walks (>= 1; short models)
+ *   tiles_per_item  G >= 1: every wave walks a group of G adjacent tiles (short models); G < -1: groups of -G tiles, but a
+ *                   partition's last round of wave slots as single tiles
  *   block_tails     0 = never, 1 = the default rule, 2 = whatever the height of an item
  *   ordering        0 = always the generic radix sort, 1 = the bucket ordering (the default)
  * No counterpart in the reference. */
@@ -295,6 +296,27 @@ int havac_ssv_set_tuning(havac_ssv_ctx *ctx, int rows_per_block, int tiles_per_i
  *   short_rows       finest row block (a multiple of 1024; default 4096); models below twice that are never cut
  *   guide            a row block takes 1 / guide of the rows that are left (2 ... 16; default 2) */
 int havac_ssv_set_split_tuning(havac_ssv_ctx *ctx, int parts_log2, int split_rounds_x4, int short_rows, int guide);
+
+/* How a launch of this shape would hand out its tiles (the same planner havac_ssv_enqueue uses; no device is touched, so
+ * tests and tools can look at a plan anywhere).  `wave_slots`: waves the device holds at once (0 = an MI355X: 256 CUs x 24);
+ * `tuning`: up to eight values as for havac_dev_set_tuning (NULL / -1 = the library's own rule).
+ *   partitions      nparts runs of adjacent tiles of about equal work: partition k = tiles [part_begin[k], part_begin[k+1])
+ *                   of the launch's ntiles tiles; workgroup i serves partition i mod nparts
+ *   a partition's items, in this order: groups of tiles_per_group adjacent tiles (a wave walks a group; short models), single
+ *                   tiles (its last single_tiles whole tiles, and what does not fill a group), then the row blocks of its
+ *                   last cut_tiles tiles (all of them if it has fewer), row-block-major
+ *   row blocks      block b < ncuts is rows [row_cut[b], row_cut[b+1]); from block ncuts on, uniform_rows rows each;
+ *                   nrow_blocks blocks per cut tile (1: no tile of the launch is cut)
+ * No counterpart in the reference. */
+typedef struct havac_launch_plan {
+    uint32_t nrows_padded, tile_begin, ntiles;
+    uint32_t nparts, part_begin[9];
+    uint32_t tiles_per_group, single_tiles, cut_tiles;
+    uint32_t nrow_blocks, ncuts, uniform_rows, row_cut[33];
+    uint32_t workgroups;
+} havac_launch_plan;
+int havac_ssv_plan(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index, uint32_t shard_count, uint32_t wave_slots,
+                   const int32_t *tuning, uint32_t ntuning, havac_launch_plan *plan_out);
 /* How the last finished pass was ordered: *path = 0 radix sort, 1 bucket ordering, 2 bucket ordering given up for the
  * radix sort (a bucket too big for an LDS sort); the number of buckets and the largest one. */
 int havac_ssv_last_ordering(havac_ssv_ctx *ctx, int *path, uint32_t *nbuckets, uint32_t *largest_bucket);

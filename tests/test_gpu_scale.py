@@ -325,7 +325,12 @@ def test_short_models_whole_hit_list(torch_dev, oracle, nrows):
     packed = synth.random_packed(ncols, 4243)
     got, = run_shards(torch, dev, packed, model)
     assert got.size > 1000
-    assert np.array_equal(got, whole_list(oracle, packed, model))
+    want = whole_list(oracle, packed, model)
+    assert np.array_equal(got, want)
+    if nrows == 64:
+        # the experiment's item order: groups of four adjacent tiles per wave, a partition's last round of wave slots as single tiles
+        again, = run_shards(torch, dev, packed, model, tuning=dict(tiles_per_item=-4))
+        assert np.array_equal(again, want)
 
 
 @pytest.mark.parametrize("per_item", [2, 3, 8])

@@ -39,6 +39,12 @@ with open(fa, "wb") as f:
 print(f"{os.path.getsize(fa) / 1e6:.0f} MB FASTA, {n} residues, one record", flush=True)
 exe = os.path.join(ROOT, "havac_amd", "havac_benchmark")
 lengths = synth.model_lengths(4000, seed=77)
+# one throw-away run first: the first HIP process on a fresh box pays for things no later one does (driver and code-object
+# caches: hipGetDeviceCount alone took 59 ms in one process and 239 ms in another, profiles/r03i_init_probe.txt)
+warm = os.path.join(d, "warm.hmm")
+synth.write_hmm(warm, [dict(name="warm", acc="RF99999", emissions=synth.emissions_from_consensus(synth.dfam_like_model(50, 1)[1], 2), maxl=200, mu=-9.0, lam=0.71)])
+subprocess.run([exe, fa, warm], capture_output=True, text=True)
+os.remove(warm)
 print("rows models | build load run verify total [s] | run-only TCUPS | reference: HAVAC (U50)  nhmmer SSV (32 threads) [s]")
 for rows, ref_h, ref_n in zip(ROWS, REF_HAVAC, REF_NHMMER):
     hmm = os.path.join(d, f"models_{rows}.hmm")

@@ -1,5 +1,5 @@
 """The program tools/pmc_passes.sh puts behind `rocprofv3 --pmc ... --`: a few launches of the SSV kernel through the handle
-API (ctypes + numpy only, nothing is re-executed).   python3 tools/pmc_probe.py [c2|c3|c5] [dfam|nohit] [launches] [tuning]"""
+API (ctypes + numpy only, nothing is re-executed).   python3 tools/pmc_probe.py [c2|c3|c5|r<rows>] [dfam|nohit] [launches] [tuning]"""
 import os
 import sys
 
@@ -19,6 +19,9 @@ if workload == "c3":
     ncols = 10_002_432
 elif workload == "c5":
     model, cons = synth.dfam_like_model(20000, synth.SEED_MODEL)
+    ncols = 100_012_032
+elif workload.startswith("r"):                   # r<rows>: one model of that many rows x 100 Mbp
+    model, cons = synth.dfam_like_model(int(workload[1:]), synth.SEED_MODEL)
     ncols = 100_012_032
 else:
     model, cons = synth.dfam_like_model(1024, synth.SEED_MODEL)
