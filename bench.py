@@ -200,7 +200,7 @@ def measure_traffic(args):
         shutil.rmtree(out, ignore_errors=True)
     traffic = (2.0 * values["FETCH_SIZE"] + values["WRITE_SIZE"]) * 1024.0
     return traffic, (f"rocprofv3 --pmc, two passes of a child of this script: FETCH_SIZE {values['FETCH_SIZE']:.1f} KB "
-                     f"(x2: gfx950 correction, uncalibrated for 8-byte-per-lane loads), WRITE_SIZE {values['WRITE_SIZE']:.1f} KB "
+                     f"(x2: gfx950 counts half the bytes of 4-, 8- and 16-byte-per-lane loads alike, tools/fetch_calibration.hip), WRITE_SIZE {values['WRITE_SIZE']:.1f} KB "
                      "per launch")
 
 

@@ -66,6 +66,12 @@
 //    rarely (SsvRare: read from the kernarg segment where it is used), no
 //    scratch.
 //
+//  * WHO TAKES WHICH TILE: workgroup i serves partition i mod 8 -- workgroups are dealt round-robin over the eight XCDs,
+//    so a partition (a run of adjacent tiles, of equal work) lives in one L2: adjacent tiles stream the same bytes of
+//    the sequence 64 chunks apart.  Whole tiles first; where tiles are tall, only the tiles that run last are cut by
+//    rows (tapered cuts, 2 KB handed from wave to wave per cut), or -- fewer tiles than wave slots -- every tile into
+//    uniform blocks.  See "work distribution" and "items" below; the plan is made on the host (havac_dev.hip, plan_launch).
+//
 // Roofline: integer VALU issue and, at the same ceiling, LDS bandwidth (SURVEY.md
 // section 8d); HBM traffic is N/4 + 4*rows + 8*hits bytes
 // per launch, thousands of cells per byte.
