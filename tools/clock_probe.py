@@ -18,7 +18,7 @@ try:
     from havac_amd import synth, _lib                      # noqa: E402
     from havac_amd.hw_client import HavacHwClient          # noqa: E402
     L = C.CDLL(lib_path)
-    L.havac_debug_clocks.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    L.havac_debug_clocks.argtypes = [C.c_void_p, C.c_int]
     names = ["waves", "block start -> items (lane words, outside entries)", "-> tile start (ticket, item decode)",
              "-> first symbols loaded and prepared", "-> chunk loop entry (window expanded, rows + second symbols issued)",
              "-> chunk loop done", "-> tile done (step behind the last chunk / hand-off)", "-> block end reached",
@@ -34,20 +34,19 @@ try:
             c.setHitCapacity(1 << 23)
             for _ in range(3):
                 c.invokeHavacSsvAsync(); c.waitForHavacSsvAsync()
-            acc = (C.c_ulonglong * 16)()
-            L.havac_debug_clocks(acc, 1)
+            buf = np.zeros(65536 * 8, np.uint32)
+            L.havac_debug_clocks(buf.ctypes.data, 1)
             ms = []
             for _ in range(5):
                 c.invokeHavacSsvAsync(); c.waitForHavacSsvAsync()
                 ms.append(c.lastRunMs()[0])
-            L.havac_debug_clocks(acc, 1)
-            waves = acc[0] or 1
-            print(f"rows {nrows} {kind}: kernel {np.mean(ms) * 1e3:.1f} us, {waves // 5} waves per launch; cycles per wave (s_memtime, 100 MHz x ?):", flush=True)
-            total = 0
-            for k in range(1, 9):
-                total += acc[k] / waves
-                print(f"    {names[k]:75s} {acc[k] / waves:10.1f}")
-            print(f"    {'sum':75s} {total:10.1f}")
+            L.havac_debug_clocks(buf.ctypes.data, 1)
+            d = buf.reshape(65536, 8).astype(np.float64)
+            ran = d[:, 4] > 0                                   # waves that had a tile (the last launch's stamps)
+            print(f"rows {nrows} {kind}: kernel {np.mean(ms) * 1e3:.1f} us, {int(ran.sum())} waves with a tile; s_memtime ticks per wave, mean (median):", flush=True)
+            for k in range(8):
+                print(f"    {names[k + 1]:75s} {d[ran, k].mean():10.1f} ({np.median(d[ran, k]):8.1f})")
+            print(f"    {'sum':75s} {d[ran].sum(axis=1).mean():10.1f}")
     c.close()
 finally:
     shutil.copyfile(kept, lib_path)
