@@ -8,7 +8,7 @@ cp havac_amd/libhavac_dev.so tools/_bin/ab/_kept.so
 for v in $variants; do
     cp tools/_bin/ab/lib$v.so havac_amd/libhavac_dev.so
     echo "== $v" >> gpurun_out/ab_rows.log
-    timeout -k 10 200 python tools/rows_probe.py 32 64 96 128 256 1024 2>/dev/null >> gpurun_out/ab_rows.log
+    timeout -k 10 200 python tools/rows_probe.py 32 64 2>/dev/null >> gpurun_out/ab_rows.log
 done
 cp tools/_bin/ab/_kept.so havac_amd/libhavac_dev.so
 cat gpurun_out/ab_rows.log
