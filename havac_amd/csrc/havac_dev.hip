@@ -436,7 +436,7 @@ static int check_inputs(std::string& err, uint64_t nsymbols, uint32_t nrows);
 extern "C" int havac_ssv_plan(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index, uint32_t shard_count, uint32_t wave_slots,
                               const int32_t* tuning, uint32_t ntuning, havac_launch_plan* out) {
     static_assert(kMaxRowCuts + 1 == 33, "havac_launch_plan::row_cut");
-    if (!out || shard_count == 0 || shard_index >= shard_count || (!tuning && ntuning)) return HAVAC_E_ARGUMENT;
+    if (!out || shard_count == 0 || shard_index >= shard_count || (!tuning && ntuning) || wave_slots > (1u << 20)) return HAVAC_E_ARGUMENT;
     std::string err;
     if (int rc = check_inputs(err, nsymbols, nrows)) return rc;
     int v[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
