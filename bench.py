@@ -292,6 +292,19 @@ def cpu_baseline(packed: np.ndarray, model: np.ndarray, gpu_hits, cores: int, wh
     return out
 
 
+def describe_plan(ncols, nrows, rank, world, tuning):
+    """how this rank's launch hands out its tiles (havac_ssv_plan: the planner havac_ssv_enqueue uses), for the JSON line"""
+    from havac_amd.ssv import launch_plan
+    t = list(tuning or [])
+    t = [t[0] if len(t) > 0 else -1, t[1] if len(t) > 1 else -1, -1, -1] + (t[4:8] if len(t) > 4 else [])
+    p = launch_plan(ncols, nrows, rank, world, tuning=t)
+    cut = p["cut_tiles"] if p["nrow_blocks"] > 1 else 0
+    return {"tiles": p["ntiles"], "partitions": p["nparts"], "workgroups": p["workgroups"],
+            "cut_tiles_per_partition": "all" if cut >= max(b - a for a, b in zip(p["part_begin"], p["part_begin"][1:])) and cut else cut,
+            "row_blocks_per_cut_tile": p["nrow_blocks"] if cut else 0,
+            "row_blocks": [list(b) for b in p["row_blocks"][:4]] + (["..."] if len(p["row_blocks"]) > 4 else [])}
+
+
 class OrderedHits:
     """The ordered record list of a pass (a torch int64 tensor on the device, device order = segment-major) with the
     lookups the checks need."""
@@ -564,6 +577,7 @@ def main():
                 "value_strictly_serial": None if serial_ms is None else round(total_cells / serial_ms / 1e6, 2),
                 "parallelism": f"column-sharded x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} gather of hit records to rank 0" if use_dist else ""),
                 "baseline": "1739 GCUPS = reference README.md:4, 1x Alveo U50 FPGA",
+                "work_distribution": describe_plan(ncols, nrows, rank, world, tuning),
             },
             "kernel": {"name": "ssv_diag_kernel", "avg_ms": round(ssv_ms, 4), "enqueue_to_ordered_ms": round(enq_ms, 4),
                        "gcups_kernel_only": round(my_cells / kernel_s / 1e9, 1)},
