@@ -292,14 +292,15 @@ def cpu_baseline(packed: np.ndarray, model: np.ndarray, gpu_hits, cores: int, wh
     return out
 
 
-def describe_plan(ncols, nrows, rank, world, tuning):
-    """how this rank's launch hands out its tiles (havac_ssv_plan: the planner havac_ssv_enqueue uses), for the JSON line"""
+def describe_plan(ncols, nrows, rank, world, tuning, wave_slots=0):
+    """how this rank's launch hands out its tiles (havac_ssv_plan: the planner havac_ssv_enqueue uses, with the wave slots
+    of the context that launched: havac_ssv_wave_slots), for the JSON line"""
     from havac_amd.ssv import launch_plan
     t = list(tuning or [])
     t = [t[0] if len(t) > 0 else -1, t[1] if len(t) > 1 else -1, -1, -1] + (t[4:8] if len(t) > 4 else [])
-    p = launch_plan(ncols, nrows, rank, world, tuning=t)
+    p = launch_plan(ncols, nrows, rank, world, wave_slots=wave_slots, tuning=t)
     cut = p["cut_tiles"] if p["nrow_blocks"] > 1 else 0
-    return {"tiles": p["ntiles"], "partitions": p["nparts"], "workgroups": p["workgroups"],
+    return {"wave_slots": wave_slots or 256 * 24, "tiles": p["ntiles"], "partitions": p["nparts"], "workgroups": p["workgroups"],
             "cut_tiles_per_partition": "all" if cut >= max(b - a for a, b in zip(p["part_begin"], p["part_begin"][1:])) and cut else cut,
             "row_blocks_per_cut_tile": p["nrow_blocks"] if cut else 0,
             "row_blocks": [list(b) for b in p["row_blocks"][:4]] + (["..."] if len(p["row_blocks"]) > 4 else [])}
@@ -334,24 +335,37 @@ class OrderedHits:
         return part[keep].cpu().numpy().view(np.uint64)
 
 
+def gathered_list_checks(merged, counts, spans):
+    """Order, duplicates, counts and columns-per-rank of a gathered list, on the device and through the C ABI
+    (havac_ssv_check_order: one grid-stride HIP pass, no list-sized temporary, 64-bit indices).  Not torch: C4's list is
+    4.46e9 records -- beyond the 2^32 elements up to which this torch build's kernels index correctly
+    (tools/big_sort_check.py) -- and 36 GB per full-size temporary on a card that already holds the receive buffers."""
+    import torch
+    from havac_amd.ssv import check_order
+    n = int(merged.numel())
+    out = {"records": n, "counts_add_up": int(sum(counts)) == n}
+    if not out["counts_add_up"]:
+        out["device_order_no_duplicates"] = out["ranks_inside_their_columns"] = None
+        return out
+    torch.cuda.current_stream(merged.device).synchronize()
+    rep = check_order(merged.data_ptr(), n, counts, spans)
+    out["device_order_no_duplicates"] = rep["out_of_order"] == 0
+    out["ranks_inside_their_columns"] = rep["out_of_span"] == 0
+    if rep["out_of_order"]:
+        out["out_of_order"] = {"records": rep["out_of_order"], "first_index": rep["first_out_of_order"]}
+    if rep["out_of_span"]:
+        out["outside_their_rank"] = {"records": rep["out_of_span"], "first_index": rep["first_out_of_span"]}
+    return out
+
+
 def distributed_parity(hits: OrderedHits, counts, spans, packed, model, cores, stretch=200_000):
     """What rank 0 checks on the gathered list of an N > 1 run before it prints: the list is in the reference's device
-    order without duplicates; the ranks' counts add up to it; every rank's records lie inside that rank's columns; and
-    around (up to) two shard boundaries -- `stretch` columns on either side: the cut side of the left rank, the halo side
-    of the right one -- the records equal the CPU checker's, every one of them."""
+    order without duplicates; the ranks' counts add up to it; every rank's records lie inside that rank's columns
+    (gathered_list_checks: one HIP pass over the list); and around (up to) two shard boundaries -- `stretch` columns on
+    either side: the cut side of the left rank, the halo side of the right one -- the records equal the CPU checker's,
+    every one of them (slices of a few 10^5 records, looked up by bisection)."""
     from oracle import pyoracle as O
-    merged, n = hits.merged, hits.n
-    out = {"records": n, "counts_add_up": int(sum(counts)) == n}
-    seg = (merged >> 14) & 0x3FFFFFF
-    key = (seg << 38) | (((merged >> 40) & 0xFFFFFF) << 14) | (merged & 0x3FFF)      # segment | row | column: the emission order
-    out["device_order_no_duplicates"] = bool((key[1:] > key[:-1]).all().item()) if n > 1 else True
-    inside, at = True, 0
-    for (lo, hi), c in zip(spans, counts):
-        if c:
-            mine = seg[at: at + c]
-            inside = inside and int(mine.min().item()) >= lo // SEGMENT and int(mine.max().item()) < hi // SEGMENT
-        at += c
-    out["ranks_inside_their_columns"] = bool(inside)
+    out = gathered_list_checks(hits.merged, counts, spans)
     nrows, ncols = model.shape[0], packed.size * 4
     boundaries = sorted({spans[0][1], spans[-1][0]}) if len(spans) > 1 else []
     checked = []
@@ -471,6 +485,7 @@ def main():
     engine = ShardedSsv(hit_capacity, device, depth=depth, gather_when_alone=use_dist, tuning=tuning)
     if world > 1:
         engine.set_sequence_window(win_first, win_end - win_first)
+    wave_slots = engine.ctx.wave_slots()
 
     def fence():
         if use_dist:
@@ -520,9 +535,12 @@ def main():
     elapsed = time.perf_counter() - t0
     gather_ms = list(engine.gather_times())
     serial_ms, serial_timings = None, kernel_ms
+    # Everything is on the device and finished (fence): the records of the last pass stay where the gather (N > 1) or the
+    # ordering (N = 1) left them -- no copy; `merged` keeps that one buffer alive -- and every other buffer of the pipelined
+    # engine is given back before anything else is allocated.  Rank 0 of `--gpus 8 --workload c4` holds 36 GB of records per receive buffer (DESIGN.md section 6
+    # has the sum); the checks below allocate nothing of that size.
+    engine.release()
     if depth > 1:       # the same steps strictly one after the other, for the record (not `value`)
-        if rank == 0 and merged is not None:
-            merged = merged.clone()
         serial = ShardedSsv(hit_capacity, device, depth=1, gather_when_alone=use_dist, tuning=tuning)
         if world > 1:
             serial.set_sequence_window(win_first, win_end - win_first)
@@ -532,8 +550,10 @@ def main():
         _, serial_timings = run_steps(serial, args.steps)
         fence()
         serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        serial.close()
-    per_rank = None
+        serial.release()
+        del serial
+    torch.cuda.empty_cache()
+    per_rank, failed = None, None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -577,7 +597,7 @@ def main():
                 "value_strictly_serial": None if serial_ms is None else round(total_cells / serial_ms / 1e6, 2),
                 "parallelism": f"column-sharded x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} gather of hit records to rank 0" if use_dist else ""),
                 "baseline": "1739 GCUPS = reference README.md:4, 1x Alveo U50 FPGA",
-                "work_distribution": describe_plan(ncols, nrows, rank, world, tuning),
+                "work_distribution": describe_plan(ncols, nrows, rank, world, tuning, wave_slots),
             },
             "kernel": {"name": "ssv_diag_kernel", "avg_ms": round(ssv_ms, 4), "enqueue_to_ordered_ms": round(enq_ms, 4),
                        "gcups_kernel_only": round(my_cells / kernel_s / 1e9, 1)},
@@ -614,9 +634,20 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(packed, model, ordered.window, cores)
         print(json.dumps(out), flush=True)
+        # a run whose list failed a check is not a result: the line above says which check, the exit code says so too
+        # (a driver that reads only `value` and the exit code must not record it as good)
+        parity = out.get("distributed", {}).get("parity")
+        base = out.get("cpu_baseline")
+        if parity is not None and not parity["ok"]:
+            failed = "distributed.parity.ok is false"
+        elif base is not None and not (base["hits_match_gpu"] and base["single_thread"]["hits_match_gpu"] and
+                                       base["vectorised_port"].get("whole_hit_list_matches_gpu", base["vectorised_port"].get("stretch_matches_gpu"))):
+            failed = "cpu_baseline: the CPU checker's records differ from the GPU's"
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.exit(f"bench.py: {failed}")
 
 
 if __name__ == "__main__":

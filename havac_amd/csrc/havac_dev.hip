@@ -245,6 +245,14 @@ int plan_launch(std::string& err, const Tiling& t, uint32_t tb, uint32_t te, int
     return HAVAC_OK;
 }
 
+// hand-off slots of a launch with cut tiles (ssv_kernels.hip.h, "items": slot = partition * split_units + unit, or the tile's
+// number where every tile is cut)
+inline size_t handoff_slots(const SsvRare& L) {
+    if (L.split_units == 0) return 0;
+    if (L.split_units == 0xffffffffu) return L.ntiles;
+    return ((size_t)1 << L.parts_log2) * L.split_units;       // (< ntiles: plan_launch cuts every tile otherwise)
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -463,6 +471,12 @@ extern "C" int havac_ssv_plan(uint64_t nsymbols, uint32_t nrows, uint32_t shard_
     return HAVAC_OK;
 }
 
+extern "C" int havac_ssv_wave_slots(havac_ssv_ctx* c, uint32_t* wave_slots) {
+    if (!c || !wave_slots) return HAVAC_E_ARGUMENT;
+    *wave_slots = (uint32_t)c->resident_blocks * kWavesPerBlock;
+    return HAVAC_OK;
+}
+
 extern "C" int havac_ssv_last_ordering(havac_ssv_ctx* c, int* path, uint32_t* nbuckets, uint32_t* largest_bucket) {
     if (!c) return HAVAC_E_ARGUMENT;
     if (path) *path = c->last_order_path;
@@ -577,16 +591,20 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     const bool split = L.split_units != 0;
     if (te > tb) {
         if (split) {
-            if (c->block_flag_tiles < L.ntiles) {
+            // one hand-off slot (a count word + 2 KB of scores) per CUT tile -- the last split_units tiles of every partition, or
+            // every tile -- not per tile of the launch (a 3 Gbp genome against a tall model is 1.5 M tiles of
+            // which ~9,000 are cut; the fill below runs on every pass)
+            const size_t slots_needed = handoff_slots(L);
+            if (c->block_flag_tiles < slots_needed) {
                 HIP_TRY(c->err, hipStreamSynchronize(stream));        // an earlier pass on this stream may still use the old buffers
                 if (c->block_flags) (void)hipFree(c->block_flags);
                 if (c->block_state) (void)hipFree(c->block_state);
                 c->block_flags = c->block_state = nullptr; c->block_flag_tiles = c->block_state_tiles = 0;
-                HIP_TRY(c->err, hipMalloc(&c->block_flags, (size_t)L.ntiles * sizeof(uint32_t)));
-                HIP_TRY(c->err, hipMalloc(&c->block_state, (size_t)L.ntiles * (kRegs / 2) * 64 * sizeof(uint32_t)));
-                c->block_flag_tiles = c->block_state_tiles = L.ntiles;
+                HIP_TRY(c->err, hipMalloc(&c->block_flags, slots_needed * sizeof(uint32_t)));
+                HIP_TRY(c->err, hipMalloc(&c->block_state, slots_needed * (kRegs / 2) * 64 * sizeof(uint32_t)));
+                c->block_flag_tiles = c->block_state_tiles = slots_needed;
             }
-            HIP_TRY(c->err, hipMemsetD32Async((hipDeviceptr_t)c->block_flags, 0, (size_t)L.ntiles, stream));
+            HIP_TRY(c->err, hipMemsetD32Async((hipDeviceptr_t)c->block_flags, 0, slots_needed, stream));
             HIP_TRY(c->err, hipMemsetD32Async((hipDeviceptr_t)c->tickets, 0, kTicketCounters * kTicketStride, stream));
         }
     }
@@ -780,7 +798,10 @@ extern "C" int havac_ssv_finish_begin(havac_ssv_ctx* c) {
     if (!c) return HAVAC_E_ARGUMENT;
     if (!c->pending) { c->err = "no pass enqueued"; return HAVAC_E_LOGIC; }
     if (c->ordering) { c->err = "havac_ssv_finish_begin called twice for one pass"; return HAVAC_E_LOGIC; }
-    HIP_TRY(c->err, hipSetDevice(c->device));
+    // (every error return below ends the pass: with `pending` left set a second finish_begin would order a list that is
+    // partly records already, and set_tuning / set_sequence_window would be refused for good; order_dirty stays set, so the
+    // next pass's ordering starts from zeroed counters.  ADVICE round 3)
+    if (hipError_t e = hipSetDevice(c->device); e != hipSuccess) { c->pending = false; c->err = hip_msg("hipSetDevice", e); return HAVAC_E_RUNTIME; }
     hipError_t waited = hipEventSynchronize(c->ev[4]);
     if (waited != hipSuccess) { c->pending = false; c->err = hip_msg("hipEventSynchronize", waited); return HAVAC_E_RUNTIME; }
     const hipStream_t order = c->order_stream ? c->order_stream : c->stream;     // the kernel is done: no device-side dependency needed
@@ -794,7 +815,7 @@ extern "C" int havac_ssv_finish_begin(havac_ssv_ctx* c) {
     const uint64_t stored = c->found < c->hit_capacity ? c->found : c->hit_capacity;
     int rc = order_records(c, c->d_hits, stored, order);
     if (rc) { c->pending = false; return rc; }
-    HIP_TRY(c->err, hipEventRecord(c->ev[3], order));
+    if (hipError_t e = hipEventRecord(c->ev[3], order); e != hipSuccess) { c->pending = false; c->err = hip_msg("hipEventRecord", e); return HAVAC_E_RUNTIME; }
     c->ordering = true;
     return HAVAC_OK;
 }
@@ -848,6 +869,46 @@ extern "C" int havac_ssv_sort_hits(havac_ssv_ctx* c, uint64_t* d_hits, uint64_t 
     if (rc) return rc;
     hipLaunchKernelGGL(ssv_keys_to_records, dim3(nb), dim3(256), 0, stream, d_hits, count, 24u);
     HIP_TRY(c->err, hipGetLastError());
+    return HAVAC_OK;
+}
+
+// The check of a gathered list (hit_order.hip.h: ssv_check_order): device order without duplicates, every rank's records
+// inside that rank's columns.  Works on the device that is current; one pass, 40 bytes + 3 small tables of its own.
+extern "C" int havac_ssv_check_order(const uint64_t* d_records, uint64_t count, const uint64_t* rank_counts,
+                                     const uint64_t* span_begin, const uint64_t* span_end, uint32_t nranks, void* hip_stream,
+                                     havac_order_report* out) {
+    static_assert(sizeof(havac_order_report) == sizeof(OrderReport), "one layout on both sides of the ABI");
+    if (!out || (!d_records && count) || nranks > kMaxCheckRanks || (nranks && (!rank_counts || !span_begin || !span_end))) return HAVAC_E_ARGUMENT;
+    std::vector<uint64_t> table(3 * (size_t)nranks + 1, 0);      // rank_begin[nranks + 1], span_begin[nranks], span_end[nranks]
+    for (uint32_t r = 0; r < nranks; r++) {
+        table[r + 1] = table[r] + rank_counts[r];
+        table[nranks + 1 + r] = span_begin[r];
+        table[2 * (size_t)nranks + 1 + r] = span_end[r];
+    }
+    if (nranks && table[nranks] != count) return HAVAC_E_LENGTH;      // the ranks' counts do not add up to the list
+    const hipStream_t stream = (hipStream_t)hip_stream;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return HAVAC_E_NO_DEVICE;
+    uint64_t* d_table = nullptr; OrderReport* d_report = nullptr;
+    OrderReport report{count, 0, ~0ull, 0, ~0ull};
+    hipError_t e = hipMalloc(&d_table, table.size() * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(&d_report, sizeof(OrderReport));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_report, &report, sizeof report, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess && count) {
+        // grid-stride: a dispatch counts its work-items in 32 bits, the list may hold more records than that
+        const unsigned blocks = (unsigned)std::min<uint64_t>((count + 255) / 256, 1u << 16);
+        hipLaunchKernelGGL(ssv_check_order, dim3(blocks), dim3(256), 0, stream, d_records, count, (const uint64_t*)d_table,
+                           (const uint64_t*)(d_table + nranks + 1), (const uint64_t*)(d_table + 2 * (size_t)nranks + 1), nranks, d_report);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&report, d_report, sizeof report, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (d_table) (void)hipFree(d_table);
+    if (d_report) (void)hipFree(d_report);
+    if (e != hipSuccess) return e == hipErrorOutOfMemory ? HAVAC_E_NOMEM : HAVAC_E_RUNTIME;
+    out->records = report.records; out->out_of_order = report.out_of_order; out->first_out_of_order = report.first_out_of_order;
+    out->out_of_span = report.out_of_span; out->first_out_of_span = report.first_out_of_span;
     return HAVAC_OK;
 }
 
@@ -1158,8 +1219,13 @@ static int read_columns(havac_dev* d, T* DevicePart::*buf, uint8_t* out, uint64_
     for (uint32_t i = 0; i < nparts; i++) {
         DevicePart& p = d->parts[i];
         uint64_t b = 0, e = ncolumns;
-        if (p.win_columns) shard_columns(ncolumns, i, nparts, &b, &e);
-        else if (i > 0) break;                                   // whole copies: the first GPU has everything
+        if (p.win_columns) {
+            shard_columns(ncolumns, i, nparts, &b, &e);
+            // shards are whole segments, and every writer refuses or pads a sequence that is not (havac_dev_write_sequence:
+            // HAVAC_E_LENGTH); should a buffer ever end behind its last whole segment, the last GPU's window covers that tail
+            // and returns it rather than leaving the caller's bytes unwritten
+            if (i + 1 == nparts) e = std::min(ncolumns, p.win_first + p.win_columns);
+        } else if (i > 0) break;                                 // whole copies: the first GPU has everything
         const uint64_t from = b / columns_per_byte, to = std::min(e / columns_per_byte, nbytes);
         if (from >= to) continue;
         HIP_TRY(d->err, hipSetDevice(p.device));

@@ -378,4 +378,43 @@ void ssv_bucket_sort_large(const uint64_t* __restrict__ in, uint64_t* __restrict
     }
 }
 
+// ---- the check of a gathered list ---------------------------------------------------------------------------------------
+// What rank 0 of a sharded run asserts about the list it has gathered before it reports it (bench.py: distributed.parity):
+// the records are in the reference's emission order -- segment, then row, then column, strictly ascending, so there are no
+// duplicates either (device/HavacHls.cpp:151-152,264) -- and the records rank r contributed (count[r] of them, the lists laid
+// end to end in rank order) lie inside that rank's columns.  ONE grid-stride pass over the list, 16 bytes read per record
+// (its own and its predecessor's, which the neighbouring lane has just fetched: L1 / L2 hits), no list-sized temporary:
+// C4's gathered list is 4.46e9 records = 36 GB, more elements than a 32-bit index holds and more bytes than a second copy
+// should cost on the card that already holds the receive buffers.
+struct OrderReport {               // havac_order_report (include/havac_dev.h)
+    unsigned long long records, out_of_order, first_out_of_order, out_of_span, first_out_of_span;
+};
+constexpr uint32_t kMaxCheckRanks = 1024;
+__global__ __launch_bounds__(256)
+void ssv_check_order(const uint64_t* __restrict__ records, uint64_t n, const uint64_t* __restrict__ rank_begin /* nranks + 1 */,
+                     const uint64_t* __restrict__ span_begin, const uint64_t* __restrict__ span_end, uint32_t nranks,
+                     OrderReport* __restrict__ report) {
+    __shared__ uint64_t s_begin[kMaxCheckRanks + 1];
+    for (uint32_t k = threadIdx.x; k <= nranks; k += blockDim.x) s_begin[k] = rank_begin[k];
+    __syncthreads();
+    unsigned long long bad_order = 0, bad_span = 0, first_order = ~0ull, first_span = ~0ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t rec = records[i];
+        const uint64_t key = record_to_key(rec, 24);
+        if (i > 0 && record_to_key(records[i - 1], 24) >= key) { bad_order++; if (i < first_order) first_order = i; }
+        if (nranks) {
+            // the rank whose stretch of the list holds record i: the last r with rank_begin[r] <= i
+            uint32_t lo = 0, hi = nranks;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) / 2;
+                if (s_begin[mid] <= i) lo = mid; else hi = mid;
+            }
+            const uint64_t column = ((rec >> 14) & 0x3ffffffull) * 12288ull + (rec & 0x3fffull);
+            if (column < span_begin[lo] || column >= span_end[lo]) { bad_span++; if (i < first_span) first_span = i; }
+        }
+    }
+    if (bad_order) { atomicAdd(&report->out_of_order, bad_order); atomicMin(&report->first_out_of_order, first_order); }
+    if (bad_span) { atomicAdd(&report->out_of_span, bad_span); atomicMin(&report->first_out_of_span, first_span); }
+}
+
 }  // namespace havac

@@ -198,6 +198,18 @@ class ShardedSsv:
         self.submit(d_seq, nsymbols, d_phmm, nrows)
         return self.collect()
 
+    def release(self):
+        """Gives the device memory of every slot back: contexts with their ordering buffers, hit buffers, receive buffers.
+        The records collect() returned last stay valid for as long as the caller holds that tensor (it keeps its buffer
+        alive); everything else is freed now, not when the engine is collected.  Nothing may be in flight."""
+        if self.in_flight:
+            raise RuntimeError("passes are in flight: collect() them first")
+        for slot in self.slots:
+            slot.ctx.close()
+            slot.hits = slot.merged = None
+        self.hits = None
+        torch.cuda.empty_cache()
+
     def close(self):
         for slot in self.slots:
             slot.ctx.close()

@@ -72,6 +72,12 @@ class SsvContext:
         """the library's rule for tall tiles (include/havac_dev.h: havac_ssv_set_split_tuning); -1 = the default"""
         self._check(self._L.havac_ssv_set_split_tuning(self._h, parts_log2, split_rounds_x4, short_rows, guide))
 
+    def wave_slots(self) -> int:
+        """waves the context's device holds at once: what enqueue() hands to the planner (launch_plan(wave_slots=...))"""
+        n = C.c_uint32(0)
+        self._check(self._L.havac_ssv_wave_slots(self._h, C.byref(n)))
+        return n.value
+
     def last_ordering(self):
         """-> (path, buckets, largest bucket) of the last finished pass: path 0 radix sort, 1 bucket ordering, 2 fallback"""
         path, nb, big = C.c_int(0), C.c_uint32(0), C.c_uint32(0)
@@ -85,6 +91,33 @@ class SsvContext:
         a, b = C.c_float(0), C.c_float(0)
         self._check(self._L.havac_ssv_last_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+
+class _OrderReport(C.Structure):
+    _fields_ = [("records", C.c_uint64), ("out_of_order", C.c_uint64), ("first_out_of_order", C.c_uint64),
+                ("out_of_span", C.c_uint64), ("first_out_of_span", C.c_uint64)]
+
+
+def check_order(d_records: int, count: int, rank_counts=(), spans=(), stream: int = 0) -> dict:
+    """The check of a gathered list on the device (include/havac_dev.h: havac_ssv_check_order): `count` packed records at
+    device address `d_records`, the ranks' lists end to end; rank r contributed rank_counts[r] records and owns columns
+    spans[r] = (begin, end).  One pass, no list-sized temporary -> dict(records, out_of_order, first_out_of_order,
+    out_of_span, first_out_of_span); the two `first_*` are None when there is no such record."""
+    n = len(rank_counts)
+    if len(spans) != n:
+        raise ValueError("one column span per rank")
+    u64 = C.c_uint64 * max(1, n)
+    counts = u64(*[int(c) for c in rank_counts])
+    begin = u64(*[int(s[0]) for s in spans])
+    end = u64(*[int(s[1]) for s in spans])
+    rep = _OrderReport()
+    rc = _lib.load().havac_ssv_check_order(d_records or None, count, counts, begin, end, n, stream or None, C.byref(rep))
+    if rc != 0:
+        raise_for(rc, "the ranks' counts do not add up to the list" if rc == _lib.E_LENGTH else "havac_ssv_check_order failed")
+    none = (1 << 64) - 1
+    return {"records": rep.records, "out_of_order": rep.out_of_order,
+            "first_out_of_order": None if rep.first_out_of_order == none else rep.first_out_of_order,
+            "out_of_span": rep.out_of_span, "first_out_of_span": None if rep.first_out_of_span == none else rep.first_out_of_span}
 
 
 def shard_cells(nsymbols: int, nrows: int, shard_index: int = 0, shard_count: int = 1) -> int:

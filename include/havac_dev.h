@@ -317,6 +317,9 @@ typedef struct havac_launch_plan {
 } havac_launch_plan;
 int havac_ssv_plan(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index, uint32_t shard_count, uint32_t wave_slots,
                    const int32_t *tuning, uint32_t ntuning, havac_launch_plan *plan_out);
+/* The waves the context's device holds at once (compute units x 24): what havac_ssv_enqueue hands to the planner, and
+ * what havac_ssv_plan must be given to reproduce a launch's plan on a device that is not a whole MI355X. */
+int havac_ssv_wave_slots(havac_ssv_ctx *ctx, uint32_t *wave_slots);
 /* How the last finished pass was ordered: *path = 0 radix sort, 1 bucket ordering, 2 bucket ordering given up for the
  * radix sort (a bucket too big for an LDS sort); the number of buckets and the largest one. */
 int havac_ssv_last_ordering(havac_ssv_ctx *ctx, int *path, uint32_t *nbuckets, uint32_t *largest_bucket);
@@ -324,6 +327,23 @@ int havac_ssv_last_ordering(havac_ssv_ctx *ctx, int *path, uint32_t *nbuckets, u
 /* Sort `count` packed records in place into device order (for callers that merge
  * lists from elsewhere; the shards of havac_ssv_enqueue need no sorting, see above). */
 int havac_ssv_sort_hits(havac_ssv_ctx *ctx, uint64_t *d_hits, uint64_t count, void *hip_stream);
+
+/* The check a sharded run makes on the list it has gathered before it reports it (bench.py: distributed.parity; no
+ * counterpart in the reference, which has one device per object, host/Havac.hpp:51).  `d_records`: `count` packed records
+ * on the current device, the ranks' lists laid end to end in rank order; rank r contributed rank_counts[r] of them (the
+ * counts must add up to `count`: HAVAC_E_LENGTH otherwise) and owns columns [span_begin[r], span_end[r]) (host arrays of
+ * nranks <= 1024 entries; nranks == 0: order only).  One grid-stride pass on `hip_stream`, waited for before return;
+ * no list-sized temporary (C4: 4.46e9 records = 36 GB, beyond 32-bit indexing).  Reports how many records are not
+ * strictly greater than their predecessor in the reference's emission order -- segment, row, column
+ * (device/HavacHls.cpp:151-152,264), so a duplicate counts too -- how many lie outside their rank's columns, and the
+ * index of the first of each kind (UINT64_MAX: none). */
+typedef struct havac_order_report {
+    uint64_t records;
+    uint64_t out_of_order, first_out_of_order;
+    uint64_t out_of_span, first_out_of_span;
+} havac_order_report;
+int havac_ssv_check_order(const uint64_t *d_records, uint64_t count, const uint64_t *rank_counts, const uint64_t *span_begin,
+                          const uint64_t *span_end, uint32_t nranks, void *hip_stream, havac_order_report *report_out);
 
 /* After the stream has been synchronised: device time of the last enqueue's
  * SSV kernel and of the whole enqueue, from HIP events recorded on that stream. */

@@ -199,3 +199,38 @@ def test_ssv_kernel_resources():
     functions = {line.split()[-1] for line in symbols.splitlines() if " FUNC " in line and "havac" in line}
     callees = {f for f in functions if not re.match(r"^_ZN5havac\d+ssv_[a-z_]+E", f)}      # the kernels are havac::ssv_*
     assert all(("flush_full" in f) or ("trace_cells_of_step" in f) for f in callees), sorted(callees)
+
+
+def _device_isa(tmpdir):
+    """the gfx950 ISA of havac_dev.hip with the compiler's block names kept (what tools/asm_chunk.py finds its regions by):
+    a device-only compile, ~12 s"""
+    import subprocess
+    out = os.path.join(tmpdir, "havac_dev.s")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-fno-discard-value-names", "-S",
+                    "-o", out, os.path.join(ROOT, "havac_amd", "csrc", "havac_dev.hip")], check=True, capture_output=True, cwd=tmpdir)
+    return out
+
+
+def test_ssv_kernel_instruction_mix(tmp_path):
+    """The hot loop's instruction mix, asserted from the disassembly (the register allocation at exactly
+    80 VGPRs is one unrelated edit away from breaking, and VGPR count / scratch alone do not show a loop that got longer).
+    One 32-step chunk on its usual path -- no matrix edge, four-step windows, no hit -- is 16 registers x 32 steps = 512
+    `v_pk_add_i16 ... clamp` and at most 620 vector instructions in all (72 for the hit tests, 15
+    window expansions, 5 `v_perm` + a handful for the tables); 256 `ds_read_b64` in the windows; nothing from scratch."""
+    import importlib.util
+    import shutil
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc is not installed here")
+    spec = importlib.util.spec_from_file_location("asm_chunk", os.path.join(ROOT, "tools", "asm_chunk.py"))
+    asm_chunk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(asm_chunk)
+    isa = _device_isa(str(tmp_path))
+    mix = asm_chunk.chunk_mix(isa, "_ZN5havac15ssv_diag_kernel")
+    chunk, windows = mix["chunk"], mix["windows"]
+    valu = asm_chunk.total(chunk, ("v_",))
+    assert chunk["v_pk_add_i16"] == 512, dict(chunk)
+    assert valu <= 620, (valu, {k: n for k, n in chunk.items() if k.startswith("v_")})
+    assert windows["ds_read_b64"] == 256, dict(windows)
+    assert asm_chunk.total(chunk, ("scratch_",)) == 0 and asm_chunk.total(chunk, ("v_readlane", "v_writelane")) == 0, dict(chunk)
+    # the hit test: one OR tree + one compare per four-step window, on the vector unit; everything else of a window is adds
+    assert chunk["v_or3_b32"] + chunk["v_bitop3_b32"] + chunk["v_cmp_ne_u32_e64"] <= 72, dict(chunk)

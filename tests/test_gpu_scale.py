@@ -544,3 +544,137 @@ def test_row_cut_table_overflows_into_uniform_blocks(torch_dev, oracle):
     got = hits[:n].cpu().numpy().view(np.uint64)
     assert got.size == want.size and np.array_equal(got, want)
     ctx.close()
+
+
+def _synthetic_gathered_list(torch, dev, nseg, per_segment, world):
+    """A device-ordered list of nseg * per_segment records, laid out like the gathered list of `world` ranks over a database
+    of nseg segments: record i lies in segment i // per_segment; inside a segment rows ascend and, inside a row, columns.
+    Filled in slices of 2^27 records (every torch kernel stays far below 2^32 elements) -> (tensor, counts, spans)."""
+    from havac_amd.ssv import shard_columns
+    n = nseg * per_segment
+    t = torch.empty(n, dtype=torch.int64, device=dev)
+    step = 1 << 27
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        i = torch.arange(a, b, dtype=torch.int64, device=dev)
+        seg, j = i // per_segment, i % per_segment
+        row, col = j >> 2, (j & 3) * 3000 + (j >> 2) % 1000
+        t[a:b] = col | (seg << 14) | (row << 40)
+    spans = [shard_columns(nseg * synth.SEGMENT, r, world) for r in range(world)]
+    counts = [(hi - lo) // synth.SEGMENT * per_segment for lo, hi in spans]
+    assert sum(counts) == n
+    return t, counts, spans
+
+
+def _swap(torch, t, i):
+    pair = t[i: i + 2].clone()
+    t[i: i + 2] = pair.flip(0)
+
+
+@pytest.mark.parametrize("nseg,per_segment", [(977, 211), (81_381, 54_067)])
+def test_gathered_list_check_survives_c4s_own_list(torch_dev, nseg, per_segment):
+    """What rank 0 of `bench.py --gpus 8 --workload c4` asserts about the 4.46e9 records it has gathered (VERDICT round 3,
+    item 1): through the C ABI (havac_ssv_check_order: one grid-stride HIP pass, 64-bit indices, no list-sized temporary) and
+    through bench.py's own routine.  A synthetic device-ordered list of 4.40e9 records (35 GB) with eight rank spans on ONE
+    GPU -> all flags true; one pair of records swapped beyond element 2^32 -> exactly the order flag false, at that index; the
+    boundary between two ranks' stretches shifted by one record (a record of rank 5 counted as rank 4's) -> exactly the
+    columns flag false, at that index.  The small case is the same with everything below 2^18."""
+    torch, dev = torch_dev
+    import importlib.util
+    import os
+    from havac_amd.ssv import check_order
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("havac_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    world = 8
+    t, counts, spans = _synthetic_gathered_list(torch, dev, nseg, per_segment, world)
+    n = int(t.numel())
+    big = n > (1 << 32)
+    assert big == (nseg > 1000) and (not big or n >= 4_400_000_000)
+    torch.cuda.synchronize(dev)
+    free_before, _ = torch.cuda.mem_get_info(dev)
+
+    clean = check_order(t.data_ptr(), n, counts, spans)
+    assert clean == {"records": n, "out_of_order": 0, "first_out_of_order": None, "out_of_span": 0, "first_out_of_span": None}
+    out = bench.gathered_list_checks(t, counts, spans)
+    assert out["counts_add_up"] and out["device_order_no_duplicates"] and out["ranks_inside_their_columns"]
+    free_after, _ = torch.cuda.mem_get_info(dev)
+    assert free_before - free_after < (64 << 20)            # no list-sized temporary was allocated (and kept) by the check
+
+    # (a) two neighbours swapped -- beyond element 2^32 in the big case -- inside one segment
+    i0 = ((1 << 32) + 123_456 if big else n // 2) // per_segment * per_segment + 7
+    _swap(torch, t, i0)
+    rep = check_order(t.data_ptr(), n, counts, spans)
+    assert rep["out_of_order"] == 1 and rep["first_out_of_order"] == i0 + 1 and rep["out_of_span"] == 0
+    out = bench.gathered_list_checks(t, counts, spans)
+    assert out["device_order_no_duplicates"] is False and out["ranks_inside_their_columns"] is True
+    assert out["out_of_order"] == {"records": 1, "first_index": i0 + 1}
+    # a duplicate is out of order too
+    saved = t[i0 + 5].clone()
+    t[i0 + 5] = t[i0 + 4]
+    assert check_order(t.data_ptr(), n)["out_of_order"] == 2
+    t[i0 + 5] = saved
+    _swap(torch, t, i0)
+    assert check_order(t.data_ptr(), n, counts, spans)["out_of_order"] == 0
+
+    # (b) the first record of rank 5 counted as rank 4's: it lies outside rank 4's columns
+    moved = list(counts)
+    moved[4] += 1
+    moved[5] -= 1
+    boundary = sum(counts[:5])
+    assert not big or boundary > (1 << 31)
+    rep = check_order(t.data_ptr(), n, moved, spans)
+    assert rep["out_of_span"] == 1 and rep["first_out_of_span"] == boundary and rep["out_of_order"] == 0
+    out = bench.gathered_list_checks(t, moved, spans)
+    assert out["device_order_no_duplicates"] is True and out["ranks_inside_their_columns"] is False
+    assert out["outside_their_rank"] == {"records": 1, "first_index": boundary}
+
+    # (c) both at once; counts that do not add up are refused, not checked
+    _swap(torch, t, i0)
+    out = bench.gathered_list_checks(t, moved, spans)
+    assert out["device_order_no_duplicates"] is False and out["ranks_inside_their_columns"] is False
+    short = list(counts)
+    short[7] -= 1
+    assert bench.gathered_list_checks(t, short, spans)["counts_add_up"] is False
+    with pytest.raises(Exception):
+        check_order(t.data_ptr(), n, short, spans)
+    del t
+    torch.cuda.empty_cache()
+
+
+def test_gathered_list_check_against_numpy(torch_dev, oracle):
+    """havac_ssv_check_order on random lists with random damage, against the same definition in numpy: records out of the
+    reference's emission order (device/HavacHls.cpp:151-152,264), duplicates, records outside their rank's columns."""
+    torch, dev = torch_dev
+    from havac_amd.ssv import check_order, shard_columns
+    rng = np.random.default_rng(99)
+    for trial in range(12):
+        nseg, world = int(rng.integers(8, 400)), int(rng.integers(1, 9))
+        n = int(rng.integers(2, 200_000))
+        rows = rng.integers(0, 1 << 24, size=n, dtype=np.uint64)
+        cols = rng.integers(0, nseg * synth.SEGMENT, size=n, dtype=np.uint64)
+        recs = oracle.device_order(np.unique(oracle.pack_hits(rows, cols)))
+        n = recs.size
+        for _ in range(int(rng.integers(0, 6))):                                    # damage: copy a record somewhere else
+            a, b = rng.integers(0, n, size=2)
+            recs[a] = recs[b]
+        spans = [shard_columns(nseg * synth.SEGMENT, r, world) for r in range(world)]
+        r_rows, r_cols = oracle.unpack_hits(recs)
+        seg = r_cols // np.uint64(synth.SEGMENT)
+        key = (seg << np.uint64(38)) | (r_rows.astype(np.uint64) << np.uint64(14)) | (r_cols % np.uint64(synth.SEGMENT))
+        bad_order = (np.nonzero(key[1:] <= key[:-1])[0] + 1).tolist()
+        # rank stretches: cut the list at random places
+        cuts = np.sort(rng.integers(0, n + 1, size=world - 1)).tolist()
+        counts = [b - a for a, b in zip([0] + cuts, cuts + [n])]
+        owner = np.repeat(np.arange(world), counts)
+        lo = np.array([s[0] for s in spans], dtype=np.uint64)[owner]
+        hi = np.array([s[1] for s in spans], dtype=np.uint64)[owner]
+        bad_span = np.nonzero((r_cols < lo) | (r_cols >= hi))[0]
+        t = torch.from_numpy(recs.view(np.int64).copy()).to(dev)
+        rep = check_order(t.data_ptr(), n, counts, spans)
+        assert rep["records"] == n and rep["out_of_order"] == len(bad_order) and rep["out_of_span"] == bad_span.size, trial
+        assert rep["first_out_of_order"] == (bad_order[0] if bad_order else None)
+        assert rep["first_out_of_span"] == (int(bad_span[0]) if bad_span.size else None)
+    empty = check_order(0, 0)
+    assert empty["records"] == 0 and empty["out_of_order"] == 0
