@@ -205,6 +205,15 @@ def measure_traffic(args):
 
 
 # ---- CPU baseline -------------------------------------------------------------------------------------------------
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            names = [line.split(":", 1)[1].strip() for line in f if line.startswith("model name")]
+        return f"{names[0]} ({len(names)} logical CPUs visible)" if names else "unknown"
+    except OSError:
+        return "unknown"
+
+
 def cpu_baseline(packed: np.ndarray, model: np.ndarray, gpu_hits, cores: int, whole_list_limit_cells=6e12):
     """Time the CPU path on a bounded sample -- the first columns of the database against the first `R` rows of the
     model (all of them up to 20000 rows; a 4096-row prefix of a taller collection, which is self-contained because
@@ -248,6 +257,9 @@ def cpu_baseline(packed: np.ndarray, model: np.ndarray, gpu_hits, cores: int, wh
         "sample": f"first {sample_cols} columns x first {R} of {nrows} rows of the same workload ({cells:.3g} cells, {dt:.1f} s wall, "
                   f"{len(blocks)} threads each a column block with a {R - 1}-column left halo)",
         "hits_match_gpu": match, "hits_in_sample": int(cpu_hits.size),
+        # the CPU and the build of what was timed, next to the core count
+        "cpu_model": cpu_model(), "compiler": O.build_info(reference=use_ref),
+        "compiler_vectorised_port": O.build_info(reference=False),
     }
     # SURVEY.md 8d's other CPU figure: the reference-shaped loop nest (test/softSsv/SoftSsv.cpp:31-62) on ONE core
     one_cols = int(min(sample_cols, max(40_000, 1.5e9 / R))) // 4 * 4
@@ -622,7 +634,9 @@ def main():
             out["distributed"] = {
                 "world": dist.get_world_size(), "backend": dist.get_backend(),
                 "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
-                "gather": "all_gather of the counts + grouped send/recv of exactly count[r] records into one buffer on rank 0",
+                "gather": ("all_gather of the counts + grouped send/recv of exactly count[r] records into one buffer on rank 0" +
+                           (", RCCL called by libhavac_dev.so (havac_gather_*)" if backend == "nccl" and os.environ.get("HAVAC_GATHER", "c_abi") != "torch"
+                            else ", through torch.distributed")),
                 "gather_ms_rank0": round(float(np.mean(gather_ms)), 4) if gather_ms else None,
                 "per_rank": per_rank,
             }
@@ -645,6 +659,8 @@ def main():
             failed = "cpu_baseline: the CPU checker's records differ from the GPU's"
     if use_dist:
         dist.barrier()
+        from havac_amd.dist import close_c_gathers
+        close_c_gathers()
         dist.destroy_process_group()
     if failed:
         sys.exit(f"bench.py: {failed}")

@@ -68,6 +68,13 @@ SIGNATURES = {
     "havac_ssv_shard_cells": (C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
     "havac_ssv_shard_columns": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32,
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "havac_gather_rccl_version": (C.c_int, [C.POINTER(C.c_int)]),
+    "havac_gather_unique_id": (C.c_int, [C.c_void_p]),
+    "havac_gather_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "havac_gather_counts": (C.c_int, [_vp, C.c_int64, C.c_void_p, C.c_void_p]),
+    "havac_gather_records": (C.c_int, [_vp, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "havac_gather_last_error": (C.c_char_p, [_vp]),
+    "havac_gather_destroy": (None, [_vp]),
     "havac_ssv_ctx_last_error": (C.c_char_p, [_vp]),
     "havac_dev_version": (C.c_char_p, []),
 }

@@ -273,19 +273,21 @@ vector<HavacHit> Havac::getHitsFromFinishedRun() {
     check(havac_dev_num_hits64(dev_, &n));
     rawHits_.assign(n, 0);
     if (n) check(havac_dev_read_hits64(dev_, rawHits_.data(), n));
-    // both strands: a record of the second half is the record at (column - forwardColumns_) of the first
-    vector<uint64_t> forward = rawHits_;
-    vector<bool> reverse(rawHits_.size(), false);
-    if (bothStrands_) {
-        for (size_t i = 0; i < forward.size(); i++) {
-            uint64_t column = ((forward[i] >> 14) & 0x3ffffffull) * 12288ull + (forward[i] & 0x3fffull);
-            if (column >= forwardColumns_) {
-                column -= forwardColumns_;
-                reverse[i] = true;
-                forward[i] = (forward[i] & ~((1ull << 40) - 1)) | ((column / 12288ull) << 14) | (column % 12288ull);
-            }
-        }
-    }
+    // both strands: a record of the second half is the record at (column - forwardColumns_) of the first.  Folded record by
+    // record where it is resolved: no second copy of the list and no flag per record (with one strand -- the reference's
+    // mode -- nothing at all is done: C4's list is 36 GB)
+    const bool bothStrands = bothStrands_;
+    const uint64_t forwardColumns = forwardColumns_;
+    auto fold = [bothStrands, forwardColumns](uint64_t rec, bool *isReverse) -> uint64_t {
+        *isReverse = false;
+        if (!bothStrands) return rec;
+        uint64_t column = ((rec >> 14) & 0x3ffffffull) * 12288ull + (rec & 0x3fffull);
+        if (column < forwardColumns) return rec;
+        column -= forwardColumns;
+        *isReverse = true;
+        return (rec & ~((1ull << 40) - 1)) | ((column / 12288ull) << 14) | (column % 12288ull);
+    };
+    const vector<uint64_t> &raw = rawHits_;
     auto mirror = [&](HavacHit &h, bool isReverse) {
         if (!isReverse) return;
         h.reverseStrand = true;
@@ -294,15 +296,17 @@ vector<HavacHit> Havac::getHitsFromFinishedRun() {
     };
     if (!boundaryMode_) {
         vector<uint32_t> sums = generatePhmmLenPrefixSums();
-        return resolveAll(forward.size(), [&](size_t i, HavacHit *hit) {
-            if (!resolveOne(forward[i], i, fastaVector, sums, hit)) return false;
-            mirror(*hit, reverse[i]);
+        return resolveAll(raw.size(), [&](size_t i, HavacHit *hit) {
+            bool isReverse;
+            if (!resolveOne(fold(raw[i], &isReverse), i, fastaVector, sums, hit)) return false;
+            mirror(*hit, isReverse);
             return true;
         });
     }
     // boundary mode: records and models have their own start tables (separators in between)
-    return resolveAll(forward.size(), [&](size_t i, HavacHit *hit) {
-        const uint64_t rec = forward[i];
+    return resolveAll(raw.size(), [&](size_t i, HavacHit *hit) {
+        bool isReverse;
+        const uint64_t rec = fold(raw[i], &isReverse);
         const uint64_t column = ((rec >> 14) & 0x3ffffffull) * 12288ull + (rec & 0x3fffull);
         const uint32_t row = (uint32_t)(rec >> 40);
         size_t j = std::upper_bound(recordStarts_.begin(), recordStarts_.end(), column) - recordStarts_.begin();
@@ -312,7 +316,7 @@ vector<HavacHit> Havac::getHitsFromFinishedRun() {
         if (column - recordStarts_[j] >= recordLengths_[j]) return false;                     // separator or padding column
         if (row - modelStarts_[k] >= p7HmmList->phmms[k].header.modelLength) return false;    // separator row
         *hit = HavacHit(column - recordStarts_[j], (uint32_t)j, row - modelStarts_[k], (uint32_t)k);
-        mirror(*hit, reverse[i]);
+        mirror(*hit, isReverse);
         return true;
     });
 }

@@ -11,6 +11,10 @@ backend is "nccl"; the same code runs over gloo on CPU tensors in the tests) and
 rank 0 never sorts.  The reference has no multi-device path at all
 (host/Havac.hpp:51: one deviceIndex per object).
 
+On the nccl backend the gather is libhavac_dev.so's own (include/havac_dev.h level 3, havac_gather_*: RCCL called behind
+the C ABI; torch.distributed only carries the communicator's 128-byte id); over gloo -- the CPU tests, rehearsals of
+several ranks on one GPU -- the same exchange goes through torch.distributed's point-to-point operations.
+
 The gather is variable-length: after one all_gather of the per-rank counts
 (8 B per rank) every rank r > 0 sends exactly its `count[r]` records and rank 0
 receives each list straight into ONE buffer of sum(count) records at the
@@ -24,10 +28,107 @@ rank raises afterwards, so no rank is left waiting inside a collective.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+
 import torch
 import torch.distributed as dist
 
 FAILED = -1      # count reported by a rank whose pass raised
+
+
+class RcclGather:
+    """The gather behind the C ABI (include/havac_dev.h, level 3: havac_gather_*): RCCL called from libhavac_dev.so, no torch
+    type and no torch kernel anywhere near the records (C4's gathered list is 4.46e9 of them, beyond the 2^32 elements up to
+    which this torch build's kernels index correctly).  torch.distributed is only the side channel for the 128-byte id."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes):
+        from . import _lib
+        self._L = _lib.load()
+        self.rank, self.world = rank, world
+        h = C.c_void_p()
+        rc = self._L.havac_gather_create(rank, world, C.c_char_p(unique_id), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"havac_gather_create failed ({rc}): RCCL could not be loaded or the communicator could not be made")
+        self._h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        from . import _lib
+        buf = C.create_string_buffer(128)
+        rc = _lib.load().havac_gather_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError(f"havac_gather_unique_id failed ({rc}): librccl.so.1 could not be loaded")
+        return buf.raw
+
+    @staticmethod
+    def rccl_version() -> int:
+        from . import _lib
+        v = C.c_int(0)
+        rc = _lib.load().havac_gather_rccl_version(C.byref(v))
+        return v.value if rc == 0 else 0
+
+    def _check(self, rc):
+        if rc != 0:
+            from .hw_client import raise_for
+            raise_for(rc, (self._L.havac_gather_last_error(self._h) or b"").decode())
+
+    def counts(self, my_count: int, stream: int = 0):
+        out = (C.c_int64 * self.world)()
+        self._check(self._L.havac_gather_counts(self._h, my_count, out, stream or None))
+        return list(out)
+
+    def records(self, d_records: int, d_out: int = 0, out_capacity: int = 0, stream: int = 0):
+        self._check(self._L.havac_gather_records(self._h, d_records or None, d_out or None, out_capacity, stream or None))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.havac_gather_destroy(self._h)
+            self._h = None
+
+
+_c_gathers = {}     # process group -> RcclGather (a communicator is made once per process and group)
+
+
+def c_gather(group=None):
+    """The process's RcclGather for `group`, made on first use (collective: every rank of the group calls this at the same
+    point): rank 0 draws the id, torch.distributed carries it to the others."""
+    key = id(group) if group is not None else None
+    g = _c_gathers.get(key)
+    if g is None:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [RcclGather.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        g = _c_gathers[key] = RcclGather(rank, world, box[0])
+    return g
+
+
+def close_c_gathers():
+    """collective (ncclCommDestroy): before the process group goes away"""
+    for g in _c_gathers.values():
+        g.close()
+    _c_gathers.clear()
+
+
+def _gather_hits_c(local_hits: torch.Tensor, local_count: int, group, out):
+    """gather_hits over havac_gather_* (the nccl backend's path): counts by one all-gather, then grouped send / receive of
+    exactly count[r] records into ONE buffer on rank 0, all of it enqueued by libhavac_dev.so behind the current stream."""
+    g = c_gather(group)
+    stream = torch.cuda.current_stream(local_hits.device).cuda_stream
+    counts = g.counts(local_count, stream)
+    bad = [r for r, c in enumerate(counts) if c < 0]
+    if bad:
+        raise ShardFailure(f"the pass failed on rank(s) {bad}; no records were gathered")
+    total = sum(counts)
+    if g.rank != 0:
+        g.records(local_hits.data_ptr(), 0, 0, stream)
+        return None, counts
+    if out is not None and out.device == local_hits.device and out.numel() >= total:
+        merged = out[:total]
+    else:
+        merged = torch.empty(total, dtype=local_hits.dtype, device=local_hits.device)
+    g.records(local_hits.data_ptr(), merged.data_ptr(), merged.numel(), stream)
+    return merged, counts
 
 
 class ShardFailure(RuntimeError):
@@ -39,6 +140,10 @@ def gather_hits(local_hits: torch.Tensor, local_count: int, group=None, out: tor
     `local_count` valid; `local_count` = FAILED if this rank's pass raised).  Returns
     (records concatenated in rank order, per-rank counts) on rank 0 and (None, counts)
     elsewhere.  `out`: optional receive buffer on rank 0 (used when it is large enough)."""
+    if dist.get_backend(group) == "nccl" and os.environ.get("HAVAC_GATHER", "c_abi") != "torch":
+        # the records travel through libhavac_dev.so's own RCCL calls (HAVAC_GATHER=torch: the same exchange through
+        # torch.distributed's point-to-point operations, kept for comparison)
+        return _gather_hits_c(local_hits, local_count, group, out)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     out_dev = local_hits.device

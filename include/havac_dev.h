@@ -7,7 +7,7 @@
  * Plain pointers and sizes only; no C++, HIP or torch types cross it.  The
  * reference-side binding a maintainer would add is shown in INTEGRATION.md.
  *
- * Two levels are exported by libhavac_dev.so:
+ * Three levels are exported by libhavac_dev.so (the third -- the RCCL gather of a sharded run -- at the end of this file):
  *
  *  1. havac_dev_*   one opaque handle per `Havac` object; one entry point per
  *                   HavacHwClient method the `Havac` class calls
@@ -360,6 +360,40 @@ int havac_ssv_shard_columns(uint64_t nsymbols, uint32_t shard_index, uint32_t sh
                             uint64_t *col_begin, uint64_t *col_end);
 
 const char *havac_ssv_ctx_last_error(havac_ssv_ctx *ctx);
+
+/* ------------------------------------------------------------------------
+ * Level 3: the one exchange of a sharded run -- an RCCL gather of the hit records to rank 0
+ * ---------------------------------------------------------------------- */
+/* BASELINE.json north_star: "... a thin C-ABI HIP layer ... shards embarrassingly across the 8 GPUs of one node with only
+ * an RCCL gather of HavacHit records over xGMI at the end".  No counterpart in the reference (one deviceIndex per object,
+ * host/Havac.hpp:51).  One process per GPU: every rank runs havac_ssv_enqueue / havac_ssv_finish on its shard; because
+ * shards are whole segments, the ranks' ordered lists laid end to end in rank order are the reference's device order
+ * (device/HavacHls.cpp:151-152,264), so rank 0 receives and never sorts.  librccl is bound at run time (the copy already in
+ * the process, else the system's): a single-GPU caller never loads it.
+ *
+ *   havac_gather_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks over any side
+ *                            channel (a file, a socket, torch.distributed's store)
+ *   havac_gather_create      collective: every rank, on its own current device, with the same id (ncclCommInitRank)
+ *   havac_gather_counts      collective, step 1 of a gather: ncclAllGather of one int64 per rank -- the records its pass left, or
+ *                            a negative number if its pass failed; counts_out (host, `world` entries) is the same on every rank.
+ *                            The one host wait of a gather.  A rank that sees a negative count skips step 2 (every rank does).
+ *   havac_gather_records     collective, step 2: rank r > 0 sends exactly its count records (ncclSend), rank 0 receives each list
+ *                            straight into d_out at the exclusive-scan offset of its rank (ncclRecv, one group) and copies its own:
+ *                            d_out[0 .. sum(counts)) is the whole list in device order.  Nothing is padded, nothing concatenated
+ *                            afterwards; rank 0 sizes d_out from counts_out.  Enqueued behind what `hip_stream` holds, on the
+ *                            communicator's own low-priority stream; `hip_stream` is made to wait for it, the host is not.
+ *                            d_out / out_capacity are ignored on ranks > 0.  A receive buffer that is too small is refused on
+ *                            rank 0 before anything is posted (HAVAC_E_LENGTH) and leaves the communicator unusable.
+ *   havac_gather_destroy     collective in the good case (ncclCommDestroy); aborts a broken communicator. */
+#define HAVAC_GATHER_ID_BYTES 128
+typedef struct havac_gather havac_gather;
+int havac_gather_rccl_version(int *version);
+int havac_gather_unique_id(uint8_t id[HAVAC_GATHER_ID_BYTES]);
+int havac_gather_create(uint32_t rank, uint32_t world, const uint8_t id[HAVAC_GATHER_ID_BYTES], havac_gather **out);
+int havac_gather_counts(havac_gather *g, int64_t my_count, int64_t *counts_out, void *hip_stream);
+int havac_gather_records(havac_gather *g, const uint64_t *d_records, uint64_t *d_out, uint64_t out_capacity, void *hip_stream);
+const char *havac_gather_last_error(havac_gather *g);
+void havac_gather_destroy(havac_gather *g);
 
 /* Library self-description, e.g. "havac_dev 0.1 gfx950". */
 const char *havac_dev_version(void);

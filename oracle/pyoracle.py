@@ -69,6 +69,15 @@ def lib():
     return _lib
 
 
+def build_info(reference: bool = False) -> str:
+    """'<compiler> <version> <flags>' of liboracle.so, or of _ref/libsoftssv_ref.so (the reference's softSsv)"""
+    L = ref() if reference else lib()
+    fn = L.softssv_ref_build_info if reference else L.havac_oracle_build_info
+    fn.restype = C.c_char_p
+    fn.argtypes = []
+    return fn().decode()
+
+
 def ref_available() -> bool:
     return os.path.isfile(os.path.join(_HERE, "_ref", "libsoftssv_ref.so"))
 

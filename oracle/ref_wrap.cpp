@@ -14,7 +14,15 @@
 
 #include "SoftSsv.h" /* from -I$(REFERENCE)/test/softSsv */
 
+#ifndef HAVAC_BUILD_FLAGS
+#define HAVAC_BUILD_FLAGS "?"
+#endif
+
 extern "C" {
+
+/* compiler and flags this object -- the reference's SoftSsv.cpp with it -- was built with (bench.py: cpu_baseline.compiler;
+ * SURVEY.md section 8d asks for it next to the core count) */
+const char *softssv_ref_build_info(void) { return "g++ " __VERSION__ " " HAVAC_BUILD_FLAGS; }
 
 /* Runs the reference on one-symbol-per-byte input and returns the number of
  * hits.  Up to `cap` hits are written as (row << 32 | column) in the

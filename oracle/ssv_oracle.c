@@ -140,6 +140,12 @@ static int cmp_u64(const void *a, const void *b) {
     return (x > y) - (x < y);
 }
 
+#ifndef HAVAC_BUILD_FLAGS
+#define HAVAC_BUILD_FLAGS "?"
+#endif
+/* compiler and flags of this object (bench.py: cpu_baseline.compiler) */
+const char *havac_oracle_build_info(void) { return "gcc " __VERSION__ " " HAVAC_BUILD_FLAGS; }
+
 void havac_oracle_sort_device_order(uint64_t *hits, uint64_t count) {
     qsort(hits, (size_t)count, sizeof(uint64_t), cmp_device);
 }

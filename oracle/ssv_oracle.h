@@ -89,6 +89,9 @@ int64_t havac_oracle_ssv_fast(const uint8_t *symbols, uint64_t n, const int8_t *
  * device/HavacHls.cpp:151-152,264; device/HitReporting.cpp:178-337. */
 void havac_oracle_sort_device_order(uint64_t *hits, uint64_t count);
 
+/* "gcc <version> <flags>": how this library was built. */
+const char *havac_oracle_build_info(void);
+
 /* Sort packed records by (row, column): the order the test comparisons use. */
 void havac_oracle_sort_row_major(uint64_t *hits, uint64_t count);
 

@@ -368,19 +368,23 @@ def test_native_software_testbench(tmp_path):
     assert "ALL TESTS PASSED" in out.stdout and out.stdout.count("passed") >= 2
 
 
-def test_rccl_gather_of_hit_records_single_rank(oracle):
+@pytest.mark.parametrize("route", ["c_abi", "torch"])
+def test_rccl_gather_of_hit_records_single_rank(oracle, route, monkeypatch):
     """The collectives of the N > 1 path on the real backend (nccl = RCCL), as far as one GPU allows: a one-rank
     process group, gather_hits on device tensors issued from a side stream (what ShardedSsv does with passes in
-    flight), then the barrier and the MAX all-reduce bench.py uses."""
+    flight), then the barrier and the MAX all-reduce bench.py uses.  Route c_abi (the default on the nccl backend): the
+    records go through libhavac_dev.so's own RCCL calls (include/havac_dev.h level 3, havac_gather_*; torch.distributed only
+    carries the communicator's id); route torch: through torch.distributed's point-to-point operations."""
     import os
     import torch
     import torch.distributed as dist
-    from havac_amd.dist import gather_hits
+    from havac_amd import dist as hdist
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
+    monkeypatch.setenv("HAVAC_GATHER", route)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = "29533"
+    os.environ["MASTER_PORT"] = "29533" if route == "c_abi" else "29534"
     dev = torch.device("cuda", 0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
@@ -390,18 +394,71 @@ def test_rccl_gather_of_hit_records_single_rank(oracle):
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            merged, counts = gather_hits(buf, 1000)
+            merged, counts = hdist.gather_hits(buf, 1000)
         side.synchronize()
         assert counts == [1000]
         assert np.array_equal(merged.cpu().numpy().view(np.uint64), recs)
-        empty, counts = gather_hits(buf, 0)
+        assert (len(hdist._c_gathers) == 1) == (route == "c_abi")          # which route ran
+        empty, counts = hdist.gather_hits(buf, 0)
         assert counts == [0] and empty.numel() == 0
+        # a caller-supplied receive buffer is used when it is large enough
+        mine = torch.zeros(2048, dtype=torch.int64, device=dev)
+        merged, counts = hdist.gather_hits(buf, 1000, out=mine)
+        torch.cuda.synchronize(dev)
+        assert merged.data_ptr() == mine.data_ptr() and np.array_equal(mine[:1000].cpu().numpy().view(np.uint64), recs)
+        # a rank whose pass failed: every rank raises after the count exchange
+        with pytest.raises(hdist.ShardFailure):
+            hdist.gather_hits(buf, hdist.FAILED)
+        merged, counts = hdist.gather_hits(buf, 7)                          # ... and the communicator is still good
+        torch.cuda.synchronize(dev)
+        assert counts == [7] and np.array_equal(merged.cpu().numpy().view(np.uint64), recs[:7])
         dist.barrier()
         t = torch.tensor([1.5], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert float(t.item()) == 1.5
     finally:
+        hdist.close_c_gathers()
         dist.destroy_process_group()
+
+
+def test_rccl_gather_through_the_c_entry_points(oracle):
+    """havac_gather_* called directly (ctypes, no torch.distributed at all): the id, a one-rank communicator, counts, records
+    into a buffer of the caller's, the misuse the header names (records before counts; a receive buffer that is too small is
+    refused with HAVAC_E_LENGTH and leaves the communicator unusable)."""
+    import torch
+    from havac_amd import _lib
+    from havac_amd.dist import RcclGather
+    from havac_amd.hw_client import LengthError, LogicError
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    assert RcclGather.rccl_version() >= 20000
+    uid = RcclGather.unique_id()
+    assert len(uid) == 128 and any(uid)
+    g = RcclGather(0, 1, uid)
+    recs = oracle.pack_hits(np.arange(5000, dtype=np.uint64) % 300, np.arange(5000, dtype=np.uint64) * 7)
+    src = torch.from_numpy(recs.view(np.int64).copy()).to(dev)
+    dst = torch.zeros(8192, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with pytest.raises(LogicError):
+        g.records(src.data_ptr(), dst.data_ptr(), dst.numel(), stream)
+    assert g.counts(5000, stream) == [5000]
+    g.records(src.data_ptr(), dst.data_ptr(), dst.numel(), stream)
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(dst[:5000].cpu().numpy().view(np.uint64), recs) and int(dst[5000:].abs().sum().item()) == 0
+    assert g.counts(-1, stream) == [-1]
+    with pytest.raises(RuntimeError):
+        g.records(src.data_ptr(), dst.data_ptr(), dst.numel(), stream)
+    assert g.counts(5000, stream) == [5000]
+    with pytest.raises(LengthError):
+        g.records(src.data_ptr(), dst.data_ptr(), 100, stream)
+    with pytest.raises(LogicError):
+        g.counts(1, stream)
+    g.close()
+    # bad arguments are refused before RCCL is asked
+    h = C.c_void_p()
+    L = _lib.load()
+    assert L.havac_gather_create(3, 2, C.c_char_p(uid), C.byref(h)) == _lib.E_ARGUMENT
+    assert L.havac_gather_create(0, 0, C.c_char_p(uid), C.byref(h)) == _lib.E_ARGUMENT
 
 
 def test_sequence_packed_on_the_gpu(oracle):
