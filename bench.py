@@ -309,10 +309,11 @@ def describe_plan(ncols, nrows, rank, world, tuning, wave_slots=0):
     of the context that launched: havac_ssv_wave_slots), for the JSON line"""
     from havac_amd.ssv import launch_plan
     t = list(tuning or [])
-    t = [t[0] if len(t) > 0 else -1, t[1] if len(t) > 1 else -1, -1, -1] + (t[4:8] if len(t) > 4 else [])
+    t = [t[0] if len(t) > 0 else -1, t[1] if len(t) > 1 else -1, -1, -1] + (t[4:9] if len(t) > 4 else [])
     p = launch_plan(ncols, nrows, rank, world, wave_slots=wave_slots, tuning=t)
     cut = p["cut_tiles"] if p["nrow_blocks"] > 1 else 0
-    return {"wave_slots": wave_slots or 256 * 24, "tiles": p["ntiles"], "partitions": p["nparts"], "workgroups": p["workgroups"],
+    return {"kernel": "ssv_diag_kernel_short (5 waves per SIMD, walks of tiles, loads a tile ahead)" if p["short_kernel"] else "ssv_diag_kernel",
+            "tiles_per_walk": p["tiles_per_group"], "wave_slots": wave_slots or 256 * 24, "tiles": p["ntiles"], "partitions": p["nparts"], "workgroups": p["workgroups"],
             "cut_tiles_per_partition": "all" if cut >= max(b - a for a, b in zip(p["part_begin"], p["part_begin"][1:])) and cut else cut,
             "row_blocks_per_cut_tile": p["nrow_blocks"] if cut else 0,
             "row_blocks": [list(b) for b in p["row_blocks"][:4]] + (["..."] if len(p["row_blocks"]) > 4 else [])}
@@ -551,6 +552,7 @@ def main():
     # ordering (N = 1) left them -- no copy; `merged` keeps that one buffer alive -- and every other buffer of the pipelined
     # engine is given back before anything else is allocated.  Rank 0 of `--gpus 8 --workload c4` holds 36 GB of records per receive buffer (DESIGN.md section 6
     # has the sum); the checks below allocate nothing of that size.
+    engine_variant = engine.ctx.last_kernel_variant()
     engine.release()
     if depth > 1:       # the same steps strictly one after the other, for the record (not `value`)
         serial = ShardedSsv(hit_capacity, device, depth=1, gather_when_alone=use_dist, tuning=tuning)
@@ -611,7 +613,7 @@ def main():
                 "baseline": "1739 GCUPS = reference README.md:4, 1x Alveo U50 FPGA",
                 "work_distribution": describe_plan(ncols, nrows, rank, world, tuning, wave_slots),
             },
-            "kernel": {"name": "ssv_diag_kernel", "avg_ms": round(ssv_ms, 4), "enqueue_to_ordered_ms": round(enq_ms, 4),
+            "kernel": {"name": "ssv_diag_kernel_short" if engine_variant else "ssv_diag_kernel", "avg_ms": round(ssv_ms, 4), "enqueue_to_ordered_ms": round(enq_ms, 4),
                        "gcups_kernel_only": round(my_cells / kernel_s / 1e9, 1)},
             "roofline": {
                 "bound": "valu", "achieved": round(achieved_tiops, 2), "peak": PEAK_TIOPS_I16,

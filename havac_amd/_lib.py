@@ -60,6 +60,8 @@ SIGNATURES = {
     "havac_ssv_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "havac_ssv_set_split_tuning": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "havac_ssv_plan": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, _vp]),
+    "havac_ssv_set_kernel_variant": (C.c_int, [_vp, C.c_int]),
+    "havac_ssv_last_kernel_variant": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "havac_ssv_wave_slots": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "havac_ssv_last_ordering": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "havac_ssv_sort_hits": (C.c_int, [_vp, C.c_void_p, C.c_uint64, C.c_void_p]),

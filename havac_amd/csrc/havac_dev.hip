@@ -161,11 +161,25 @@ RowCuts plan_row_cuts(uint32_t nrows_padded, uint32_t short_rows, uint32_t guide
 //    everywhere at about the same time.  Round 2 cut EVERY tile into blocks of 8192 rows: the same balance, but a hand-off per
 //    8192 x 2048 cells was 7-9 x the bytes the problem needs on C3 and C5.  (Cutting SHORT tiles to fill the last round -- C2
 //    is 9.54 rounds -- does not pay: 2, 3, 4 row blocks per 1024-row tile took 2.20, 3.22, 4.5 ms against 2.02.);
-struct PlanTuning { int rows_per_block, tiles_per_item, parts_log2; uint32_t split_rounds_x4, short_rows, guide; };
-struct LaunchPlan { SsvRare L{}; uint32_t nblocks = 0, largest_item_rows = 0; };
+//  * short models (at most kShortItemRows rows: a tile is one to four chunks and mostly prologue) take the second instantiation
+//    of the kernel, ssv_diag_kernel_short: five waves per SIMD, every wave walks a group of kShortWalk adjacent tiles with the
+//    next tile's first loads in flight across the current one (ssv_kernels.hip.h, "the short-model variant"); a partition's last
+//    round of wave slots stays single tiles, so that the launch still ends evenly.
+constexpr int kShortWalk = 4;
+struct PlanTuning { int rows_per_block, tiles_per_item, parts_log2; uint32_t split_rounds_x4, short_rows, guide; int variant = -1; };
+struct LaunchPlan { SsvRare L{}; uint32_t nblocks = 0, largest_item_rows = 0; bool short_kernel = false; };
+// which instantiation runs a launch: the short-model one where the model is short and nothing it leaves out is asked for
+// (separator masks, the per-cell trace, row blocks); `variant`: -1 = this rule, 0 = always the standard kernel, 1 = the short
+// one wherever it is valid (tests, A/B)
+bool pick_short_kernel(const Tiling& t, int variant, bool has_mask, bool has_trace) {
+    return variant != 0 && !has_mask && !has_trace && t.nrows_padded <= kShortItemRows;
+}
 int plan_launch(std::string& err, const Tiling& t, uint32_t tb, uint32_t te, int64_t col_end, uint64_t slots, const PlanTuning& tune,
-                const uint32_t* known_part_begin /* 9 entries of an earlier plan of the same shape, or null */, LaunchPlan& plan) {
+                const uint32_t* known_part_begin /* 9 entries of an earlier plan of the same shape, or null */, LaunchPlan& plan,
+                bool short_kernel = false) {
     SsvRare& L = plan.L;
+    plan.short_kernel = short_kernel;
+    if (short_kernel) slots = slots * 5 / 6;          // five waves per SIMD instead of six
     L.first_diag = t.first_diag; L.tile_begin = tb; L.ntiles = te - tb;
     L.col_end = col_end;
     L.parts_log2 = L.ntiles >= 64 ? 3u : 0u;
@@ -203,8 +217,9 @@ int plan_launch(std::string& err, const Tiling& t, uint32_t tb, uint32_t te, int
     // 10 %, with or without the next tile's symbols fetched a tile ahead.  tiles_per_item = G > 1: every tile in a
     // group; G < -1: groups of -G tiles, but a partition's last round of wave slots as single tiles.
     uint32_t tiles_per_item = 1, single_tiles = 0;
-    if (tune.tiles_per_item >= 1 && !split) tiles_per_item = (uint32_t)tune.tiles_per_item;
-    if (tune.tiles_per_item < -1 && !split) { tiles_per_item = (uint32_t)(-tune.tiles_per_item); single_tiles = (uint32_t)((slots + nparts - 1) / nparts); }
+    const int walk = tune.tiles_per_item == -1 && short_kernel ? -kShortWalk : tune.tiles_per_item;      // (the short kernel's default: groups, the last round single)
+    if (walk >= 1 && !split) tiles_per_item = (uint32_t)walk;
+    if (walk < -1 && !split) { tiles_per_item = (uint32_t)(-walk); single_tiles = (uint32_t)((slots + nparts - 1) / nparts); }
     L.tiles_per_item = tiles_per_item; L.single_tiles = single_tiles;
     plan.nblocks = 0;
     plan.largest_item_rows = t.nrows_padded;
@@ -291,6 +306,8 @@ struct havac_ssv_ctx {
     uint64_t window_first = 0, window_columns = 0;   // the caller's sequence buffer holds only these columns (0, 0: all of them)
     // experiment knobs (havac_ssv_set_tuning): -1 = the library decides
     int tune_rows_per_block = -1, tune_tiles_per_item = -1, tune_block_tails = -1;
+    int tune_variant = -1;                     // havac_ssv_set_kernel_variant: -1 the library decides, 0 standard kernel, 1 short-model kernel where valid
+    bool last_short_kernel = false;
     // havac_ssv_set_split_tuning: partitions (-1: the library decides), rounds of wave slots whose tiles are cut (x4), finest row block, taper
     PartitionKey part_key{}; uint32_t part_begin[9] = {};            // the partitions of the last launch's shape (plan_partitions)
     uint32_t last_plan_blocks = 0, last_plan_item_rows = 0;
@@ -447,18 +464,19 @@ extern "C" int havac_ssv_plan(uint64_t nsymbols, uint32_t nrows, uint32_t shard_
     if (!out || shard_count == 0 || shard_index >= shard_count || (!tuning && ntuning) || wave_slots > (1u << 20)) return HAVAC_E_ARGUMENT;
     std::string err;
     if (int rc = check_inputs(err, nsymbols, nrows)) return rc;
-    int v[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-    for (uint32_t i = 0; i < ntuning && i < 8; i++) v[i] = tuning[i];
-    if ((v[0] > 0 && v[0] < 1024) || v[4] > 3 || (v[6] >= 0 && v[6] < 1024) || v[7] == 0 || v[7] == 1 || v[7] > 16) return HAVAC_E_ARGUMENT;
+    int v[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+    for (uint32_t i = 0; i < ntuning && i < 9; i++) v[i] = tuning[i];
+    if ((v[0] > 0 && v[0] < 1024) || v[4] > 3 || (v[6] >= 0 && v[6] < 1024) || v[7] == 0 || v[7] == 1 || v[7] > 16 || v[8] > 1) return HAVAC_E_ARGUMENT;
     const PlanTuning tune{v[0], v[1], v[4] < 0 ? -1 : v[4], v[5] < 0 ? kSplitRoundsX4 : (uint32_t)v[5],
-                          v[6] < 0 ? kShortRows : (uint32_t)v[6] / 1024u * 1024u, v[7] < 0 ? kCutGuide : (uint32_t)v[7]};
+                          v[6] < 0 ? kShortRows : (uint32_t)v[6] / 1024u * 1024u, v[7] < 0 ? kCutGuide : (uint32_t)v[7], v[8] < 0 ? -1 : v[8]};
     const Tiling t = make_tiling(nsymbols, nrows);
     uint64_t col_begin, col_end;
     shard_columns(nsymbols, shard_index, shard_count, &col_begin, &col_end);
     uint32_t tb, te;
     shard_tiles(t, nrows, col_begin, col_end, &tb, &te);
     LaunchPlan plan;
-    if (int rc = plan_launch(err, t, tb, te, (int64_t)col_end, wave_slots ? wave_slots : 256u * kBlocksPerCu * kWavesPerBlock, tune, nullptr, plan)) return rc;
+    if (int rc = plan_launch(err, t, tb, te, (int64_t)col_end, wave_slots ? wave_slots : 256u * kBlocksPerCu * kWavesPerBlock, tune, nullptr, plan,
+                             pick_short_kernel(t, tune.variant, false, false))) return rc;
     const SsvRare& L = plan.L;
     std::memset(out, 0, sizeof(*out));
     out->nrows_padded = t.nrows_padded; out->tile_begin = L.tile_begin; out->ntiles = L.ntiles;
@@ -468,6 +486,21 @@ extern "C" int havac_ssv_plan(uint64_t nsymbols, uint32_t nrows, uint32_t shard_
     out->nrow_blocks = L.ntiles ? L.nrow_blocks : 0; out->ncuts = L.ncuts; out->uniform_rows = L.uniform_rows;
     for (uint32_t i = 0; i <= (uint32_t)kMaxRowCuts; i++) out->row_cut[i] = L.row_cut[i];
     out->workgroups = plan.nblocks;
+    out->short_kernel = plan.short_kernel ? 1u : 0u;
+    return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_set_kernel_variant(havac_ssv_ctx* c, int variant) {
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (c->pending) { c->err = "a pass is in flight: change the kernel variant between passes"; return HAVAC_E_LOGIC; }
+    if (variant > 1) { c->err = "kernel variant: -1 (the library decides), 0 (standard) or 1 (short models)"; return HAVAC_E_ARGUMENT; }
+    c->tune_variant = variant < 0 ? -1 : variant;
+    return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_last_kernel_variant(havac_ssv_ctx* c, int* variant) {
+    if (!c || !variant) return HAVAC_E_ARGUMENT;
+    *variant = c->last_short_kernel ? 1 : 0;
     return HAVAC_OK;
 }
 
@@ -576,13 +609,14 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     // ---- how the tiles are handed out (plan_launch; ssv_kernels.hip.h, "items") ----
     SsvRare L{};          // the kernel's first argument: tiling, hit queue, hand-off buffers (read from the kernarg segment on demand)
     const uint64_t slots = (uint64_t)c->resident_blocks * kWavesPerBlock;
-    const PlanTuning tuning{c->tune_rows_per_block, c->tune_tiles_per_item, c->tune_parts_log2, c->tune_split_rounds_x4, c->tune_short_rows, c->tune_guide};
+    const PlanTuning tuning{c->tune_rows_per_block, c->tune_tiles_per_item, c->tune_parts_log2, c->tune_split_rounds_x4, c->tune_short_rows, c->tune_guide, c->tune_variant};
+    const bool short_kernel = pick_short_kernel(t, c->tune_variant, c->pair_mask != nullptr, c->trace_cells != nullptr);
     {
         // (the partitions are kept from pass to pass while the shape stays the same: a pass of C2 is 1.9 ms, the table takes 50,000 tiles)
         const PartitionKey key{nsymbols, nrows, col_begin, col_end, tb, te, (uint32_t)c->tune_parts_log2};
         const bool cached = key == c->part_key;
         LaunchPlan plan;
-        if (int prc = plan_launch(c->err, t, tb, te, (int64_t)col_end, slots, tuning, cached ? c->part_begin : nullptr, plan)) return prc;
+        if (int prc = plan_launch(c->err, t, tb, te, (int64_t)col_end, slots, tuning, cached ? c->part_begin : nullptr, plan, short_kernel)) return prc;
         if (!cached) { for (uint32_t k = 0; k <= 8; k++) c->part_begin[k] = plan.L.part_begin[k]; c->part_key = key; }
         L = plan.L;
         c->last_plan_blocks = plan.nblocks; c->last_plan_item_rows = plan.largest_item_rows;
@@ -639,8 +673,12 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         R.cells = c->trace_cells; R.cell_row0 = c->trace_row0; R.cell_col0 = (int64_t)c->trace_col0;
         R.cell_rows = c->trace_rows; R.cell_cols = c->trace_cols;
         const uint32_t* const safe_chunks = c->pair_mask ? (const uint32_t*)nullptr : (const uint32_t*)c->chunk_flags;
+        c->last_short_kernel = short_kernel;
         if (c->trace_cells)       // debugging: the same kernel body with the per-cell trace compiled in
             hipLaunchKernelGGL(ssv_diag_kernel_traced, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,
+                               d_sequence, (const uint32_t*)c->rows8, safe_chunks, (int64_t)nsymbols, t.nrows_padded);
+        else if (short_kernel)    // short models: five waves per SIMD, walks of tiles with their first loads a tile ahead
+            hipLaunchKernelGGL(ssv_diag_kernel_short, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,
                                d_sequence, (const uint32_t*)c->rows8, safe_chunks, (int64_t)nsymbols, t.nrows_padded);
         else
             hipLaunchKernelGGL(ssv_diag_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,
@@ -1038,11 +1076,12 @@ extern "C" int havac_dev_set_hit_capacity(havac_dev* d, uint64_t max_hits) {
 extern "C" int havac_dev_set_tuning(havac_dev* d, const int32_t* values, uint32_t count) {
     if (!d || (!values && count)) return HAVAC_E_ARGUMENT;
     if (d->has_run && !d->finished) { d->err = "cannot change the tuning during a run"; return HAVAC_E_LOGIC; }
-    int v[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-    for (uint32_t i = 0; i < count && i < 8; i++) v[i] = values[i];
+    int v[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+    for (uint32_t i = 0; i < count && i < 9; i++) v[i] = values[i];
     for (DevicePart& p : d->parts) {
         if (int rc = havac_ssv_set_tuning(p.ctx, v[0], v[1], v[2], v[3])) { d->err = havac_ssv_ctx_last_error(p.ctx); return rc; }
         if (int rc = havac_ssv_set_split_tuning(p.ctx, v[4], v[5], v[6], v[7])) { d->err = havac_ssv_ctx_last_error(p.ctx); return rc; }
+        if (int rc = havac_ssv_set_kernel_variant(p.ctx, v[8])) { d->err = havac_ssv_ctx_last_error(p.ctx); return rc; }
     }
     return HAVAC_OK;
 }

@@ -915,7 +915,24 @@ constexpr uint32_t kHandoffSpins = 1u << 26;   // x ~1 us: a minute, far beyond 
 // few temporaries.  Nothing else is kept in a VGPR through the windows: no lane number (LaneWords, fresh_lane), no
 // SGPR spills (SsvRare).  The sixth wave is worth 3 % (C2 kernel 1.93 -> 1.87 ms); a seventh (72 VGPRs) needs batches of
 // four match-word pairs and spills in the chunk epilogue.
-template <bool Trace>
+// ---- the short-model variant (Short) ---------------------------------------------------------------------------------------
+// A tile of a short model -- one to four 32-row chunks -- is mostly prologue: of the ~22,500 cycles a one-chunk tile's wave
+// lives, the chunk takes 11,900; the rest is latency in a row (kernarg loads of the item's decode, the first symbols, then
+// window + second symbols + model rows: two trips to memory one after the other) and ~2 us of empty wave slot between a
+// workgroup's end and its successor's start.  The reference's array has no such dependence on the
+// model's height (README.md:4; device/HavacHls.cpp:220-319: one row per clock whatever L is).  The second instantiation of
+// the SAME body for launches whose items are at most kShortItemRows rows:
+//   * five waves per SIMD (96 VGPRs): room for eight registers that carry loads across a whole tile;
+//   * a wave WALKS a group of adjacent tiles (SsvRare::tiles_per_item), and the first loads of tile g+1 -- its first two
+//     symbol words, its first model rows, the abort word -- are ISSUED AT THE START OF TILE g and consumed a tile later: no
+//     tile of a walk but the first waits for memory in its prologue, so the waves of a round can walk in step without
+//     stalling in step (what made walking a loss in round 3), a workgroup's start and end are paid once per group, and the
+//     item is decoded once per walk;
+//   * no separator mask, no row blocks, no trace: the host (havac_dev.hip, pick_kernel) takes the standard kernel for those.
+constexpr uint32_t kShortItemRows = 128;
+struct TileLoads { uint2 w0, w1; uint32_t r0, r1, r2, abort_word; };      // Short: what a tile's prologue needs from memory
+
+template <bool Trace, bool Short = false>
 __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
                                               const uint32_t* __restrict__ safe_chunks, const int64_t nsymbols,
                                               const uint32_t nrows_padded) {
@@ -924,7 +941,8 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
     const uint32_t lane = threadIdx.x & 63;
     // a separator mask is in use exactly when there are no chunk flags; as a 32-bit SGPR flag tested afresh (fresh_uniform), not a
     // lane mask that is copied through -- and once spilled from -- a VGPR
-    const uint32_t has_mask = opaque_uniform(safe_chunks == nullptr ? 1u : 0u);
+    // (Short: never launched with a separator mask -- a constant, and every branch on it is gone)
+    const uint32_t has_mask = Short ? 0u : opaque_uniform(safe_chunks == nullptr ? 1u : 0u);
     // readfirstlane: everything derived from the tile index is wave-uniform (SALU branches, scalar address math)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds* const lds = &wave_lds[wave];
@@ -951,11 +969,15 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
     }
 
     // ---- one item: tile `tile_in_launch` of the launch, all of its rows or (cut != 0) its row block `block` ---------------
+    TileLoads ahead{};                 // Short: the first loads of the walk's NEXT tile, in flight across the current one
     auto run_item = [&](const uint32_t tile_arg, const uint32_t block_arg /* kWholeTile: all rows */,
-                        const uint32_t slot_arg /* cut tiles: the tile's hand-off slot */) -> bool {   // false: stop (abort requested, or a hand-off never came)
+                        const uint32_t slot_arg /* cut tiles: the tile's hand-off slot */,
+                        const uint32_t fetch_ahead /* Short: 0 = this tile's first loads are issued here (the walk's first tile), 1 = they
+                                                      are in `ahead`; bit 1: issue the next tile's */) -> bool {   // false: stop (abort requested, or a hand-off never came)
         // (wave-uniform, but a division may have left them in vector registers)
-        const uint32_t tile_in_launch = __builtin_amdgcn_readfirstlane(tile_arg), block = __builtin_amdgcn_readfirstlane(block_arg);
-        const uint32_t handoff_slot = __builtin_amdgcn_readfirstlane(slot_arg);
+        const uint32_t tile_in_launch = __builtin_amdgcn_readfirstlane(tile_arg);
+        const uint32_t block = Short ? kWholeTile : __builtin_amdgcn_readfirstlane(block_arg);
+        const uint32_t handoff_slot = Short ? 0u : __builtin_amdgcn_readfirstlane(slot_arg);
         const uint32_t cut = block != kWholeTile ? 1u : 0u;
         const rare_args_t launch = rare_args();
         const uint32_t tile = launch->tile_begin + tile_in_launch;
@@ -978,16 +1000,17 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             if (p_begin < b0) p_begin = b0;
             if (p_end > b1) p_end = b1;
         }
-        if (p_begin >= p_end) return true;
+        if constexpr (!Short) { if (p_begin >= p_end) return true; }      // (Short: behind the loads of the walk's next tile, below)
         // An abort request stops every item that has not started yet: a run of short models, whose items never reach the
         // 2048-row poll below, drains at once too.  The word is read past the caches -- a trip to memory -- so the load is
         // ISSUED here and looked at behind the item's first loads (symbols, model rows), with which it travels: tested at
         // once, it cost a one-chunk tile a memory latency of its own before anything else had started.
         uint32_t abort_now = 0;
-        {
+        auto load_abort_word = [&]() -> uint32_t {
             const uint32_t* const abort_flag = rare_args()->abort_flag;
-            if (abort_flag) abort_now = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+            return abort_flag ? __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+        };
+        if constexpr (!Short) abort_now = load_abort_word();
 
         uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_window)
         // (uniform base, lane offset added where it is used: a per-lane 64-bit pointer would sit in two VGPRs through the item)
@@ -1089,11 +1112,49 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         };
         LazySymbols z;
         LaneWords mine = read_lane_words(lane_words_address);
-        fetch_symbols(p_begin, z, mine.lane8);
-        if (__builtin_amdgcn_readfirstlane(abort_now)) return false;       // (a scalar branch: every lane read the same word)
-        expand_all(C, z, std::make_integer_sequence<int, 16>{});       // -> C[16..32): the first chunk's lower half after the slide
-        ModelRows next_rows = fetch_rows(p_begin, mine);
-        fetch_symbols(p_begin + 32, z, mine.lane8);
+        ModelRows next_rows;
+        if constexpr (Short) {
+            // A tile's first loads, all in flight before anything waits: the symbols of its first two chunks, its first model
+            // rows, the abort word.  (whole tiles only: rows from the tile's own p_lo; the ranges are recomputed where the words
+            // are consumed -- scalar arithmetic -- so that only the loaded words travel)
+            auto issue_tile_loads = [&](const uint32_t t_in_launch, TileLoads& L) {
+                const rare_args_t launch2 = rare_args();
+                const int64_t t_d0 = launch2->first_diag + (int64_t)(launch2->tile_begin + t_in_launch) * kTileDiags;
+                int64_t t_lo = -t_d0 - kTileDiags;
+                if (t_lo < 0) t_lo = 0;
+                if (t_lo > (int64_t)nrows_padded) t_lo = nrows_padded;
+                const uint32_t t_begin = __builtin_amdgcn_readfirstlane((uint32_t)t_lo);
+                auto range_of = [&](int64_t rel) -> SymbolRange {
+                    SymbolRange e;
+                    e.first = t_d0 + rel;
+                    e.valid_lo = clamp_to_4096(-e.first);
+                    e.valid_hi = clamp_to_4096(nsymbols - e.first);
+                    e.edge = (uint32_t)(e.valid_lo != 0) | (uint32_t)(e.valid_hi < kTileDiags);
+                    return e;
+                };
+                uint32_t no_separators;
+                load_symbols(range_of(t_begin), mine.lane8, L.w0, no_separators);
+                const ModelRows r = fetch_rows(t_begin, mine);
+                L.r0 = r.r0; L.r1 = r.r1; L.r2 = r.r2;
+                load_symbols(range_of(t_begin + 32), mine.lane8, L.w1, no_separators);
+                L.abort_word = load_abort_word();
+            };
+            if (!(fetch_ahead & 1u)) issue_tile_loads(tile_in_launch, ahead);       // the walk's first tile: nothing was issued for it yet
+            const TileLoads now = ahead;
+            if (fetch_ahead & 2u) issue_tile_loads(tile_in_launch + 1u, ahead);     // the next tile's, a whole tile ahead of their use
+            if (p_begin >= p_end) return true;                                      // (a tile without rows: never expected inside a launch's range)
+            finish_symbols(symbol_range(p_begin), now.w0, 0u, z);
+            if (__builtin_amdgcn_readfirstlane(now.abort_word)) return false;
+            expand_all(C, z, std::make_integer_sequence<int, 16>{});
+            next_rows = ModelRows{now.r0, now.r1, now.r2, mine.sel_second, mine.entries};
+            finish_symbols(symbol_range(p_begin + 32), now.w1, 0u, z);
+        } else {
+            fetch_symbols(p_begin, z, mine.lane8);
+            if (__builtin_amdgcn_readfirstlane(abort_now)) return false;       // (a scalar branch: every lane read the same word)
+            expand_all(C, z, std::make_integer_sequence<int, 16>{});       // -> C[16..32): the first chunk's lower half after the slide
+            next_rows = fetch_rows(p_begin, mine);
+            fetch_symbols(p_begin + 32, z, mine.lane8);
+        }
         // The global loads of a chunk (12 B of model rows and 8 B of symbols per lane) are issued at the END of the chunk
         // before it and consumed at its top: no register carries them across the windows, and the latency that is
         // exposed this way is covered by the other four waves of the SIMD (measured in round 1: 2.12 ms against 2.16 ms
@@ -1102,17 +1163,20 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         bool go_on = true;                 // wave-uniform
         // one bit per chunk: may the chunk look for hits every four steps only (ssv_prepare_model)?  never with separators.
         // The word of the current 1024 rows and, loaded a whole block ahead, the next one: the test never waits for memory
-        uint32_t safe_now = safe_chunks ? safe_chunks[p_begin >> 10] : 0u;
-        uint32_t safe_next = safe_chunks ? safe_chunks[(p_begin >> 10) + 1] : 0u;
+        // (Short: a model of at most kShortItemRows rows lies inside the first flag word, and no item is long enough for a poll)
+        uint32_t safe_now = Short ? safe_chunks[0] : (safe_chunks ? safe_chunks[p_begin >> 10] : 0u);
+        uint32_t safe_next = Short ? 0u : (safe_chunks ? safe_chunks[(p_begin >> 10) + 1] : 0u);
         for (uint32_t p0 = p_begin; p0 < p_end; p0 += kChunkRows) {
-            if ((p0 & 1023) == 0 && p0 != p_begin) {
-                safe_now = safe_next;
-                safe_next = safe_chunks ? safe_chunks[(p0 >> 10) + 1] : 0u;
-            }
-            // abort: a device word, read past the caches every 2048 rows inside an item (and between items, below)
-            if (((p0 & 2047) == 0) && p0 != p_begin) {
-                const uint32_t* const abort_flag = rare_args()->abort_flag;
-                if (abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { go_on = false; break; }
+            if constexpr (!Short) {
+                if ((p0 & 1023) == 0 && p0 != p_begin) {
+                    safe_now = safe_next;
+                    safe_next = safe_chunks ? safe_chunks[(p0 >> 10) + 1] : 0u;
+                }
+                // abort: a device word, read past the caches every 2048 rows inside an item (and between items, below)
+                if (((p0 & 2047) == 0) && p0 != p_begin) {
+                    const uint32_t* const abort_flag = rare_args()->abort_flag;
+                    if (abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { go_on = false; break; }
+                }
             }
             build_tables(next_rows);
             // slide the window by 32 symbols
@@ -1175,33 +1239,40 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         // row-block-major.  (Decoded afresh for every tile of a walk -- a dozen scalar instructions: only `item` and the count
         // stay alive across a tile, and the hot loop is as short of scalar registers as of vector ones.  ONE call site of run_item:
         // with two, hipcc stops inlining it -- and a called function cannot read the kernarg segment.)
+        // (Short: decoded once per walk, and only the walk -- first tile, length -- lives across its tiles)
+        uint32_t first_tile = 0, walk = 0, block = kWholeTile, slot = 0;
         for (uint32_t g = 0;; g++) {
-            const rare_args_t plan = rare_args();
-            const uint32_t t0 = plan->part_begin[part], t1 = plan->part_begin[part + 1u];
-            const uint32_t mine = t1 - t0, cut_limit = plan->split_units;
-            const uint32_t cut_units = cut_limit < mine ? cut_limit : mine, whole = mine - cut_units;
-            const uint32_t per_group = plan->tiles_per_item, single_tiles = plan->single_tiles;
-            const uint32_t groups = per_group > 1 ? (whole - (single_tiles < whole ? single_tiles : whole)) / per_group : 0u;
-            const uint32_t singles = whole - groups * per_group;
-            // A cut tile's hand-off slot (SsvRare::block_flags / block_state): cut tile u of partition k has slot k * split_units + u
-            // -- the buffers hold the launch's CUT tiles only (C4's rank: 9,216 of 61,000 tiles; a 3 Gbp genome against a tall
-            // model: 18 MB instead of 3 GB) -- or, where every tile is cut (split_units = all ones), the tile's own number.
-            uint32_t first_tile = 0, walk = 0, block = kWholeTile, slot = 0;
-            if (item < groups) {
-                first_tile = t0 + item * per_group;
-                walk = per_group;
-            } else if (item - groups < singles) {
-                first_tile = t0 + groups * per_group + (item - groups);
-                walk = 1;
-            } else if (item - groups - singles < cut_units * plan->nrow_blocks) {
-                const uint32_t j = item - groups - singles;
-                block = j / cut_units;
-                const uint32_t unit = j - block * cut_units;
-                first_tile = t0 + whole + unit;
-                slot = cut_limit == 0xffffffffu ? first_tile : part * cut_limit + unit;
-                walk = 1;
+            if (!Short || g == 0) {
+                const rare_args_t plan = rare_args();
+                const uint32_t t0 = plan->part_begin[part], t1 = plan->part_begin[part + 1u];
+                const uint32_t mine = t1 - t0, cut_limit = plan->split_units;
+                const uint32_t cut_units = cut_limit < mine ? cut_limit : mine, whole = mine - cut_units;
+                const uint32_t per_group = plan->tiles_per_item, single_tiles = plan->single_tiles;
+                const uint32_t groups = per_group > 1 ? (whole - (single_tiles < whole ? single_tiles : whole)) / per_group : 0u;
+                const uint32_t singles = whole - groups * per_group;
+                // A cut tile's hand-off slot (SsvRare::block_flags / block_state): cut tile u of partition k has slot k * split_units + u
+                // -- the buffers hold the launch's CUT tiles only (C4's rank: 9,216 of 61,000 tiles; a 3 Gbp genome against a tall
+                // model: 18 MB instead of 3 GB) -- or, where every tile is cut (split_units = all ones), the tile's own number.
+                first_tile = 0; walk = 0; block = kWholeTile; slot = 0;
+                if (item < groups) {
+                    first_tile = t0 + item * per_group;
+                    walk = per_group;
+                } else if (item - groups < singles) {
+                    first_tile = t0 + groups * per_group + (item - groups);
+                    walk = 1;
+                } else if (item - groups - singles < cut_units * plan->nrow_blocks) {
+                    const uint32_t j = item - groups - singles;
+                    block = j / cut_units;
+                    const uint32_t unit = j - block * cut_units;
+                    first_tile = t0 + whole + unit;
+                    slot = cut_limit == 0xffffffffu ? first_tile : part * cut_limit + unit;
+                    walk = 1;
+                }
             }
-            if (g >= walk || !run_item(first_tile + g, block, slot)) break;
+            // Short: a tile's first loads are issued a tile ahead (bit 0: this tile's are in flight already; bit 1: issue the next one's)
+            const uint32_t fetch_ahead = Short ? ((g != 0 ? 1u : 0u) | (g + 1u < walk ? 2u : 0u)) : 0u;
+            // (no row blocks in a Short launch: every item is a run of whole tiles, and nothing of the hand-off is compiled in)
+            if (g >= walk || !run_item(first_tile + g, Short ? kWholeTile : block, Short ? 0u : slot, fetch_ahead)) break;
         }
     }
 
@@ -1297,6 +1368,13 @@ void ssv_diag_kernel(const SsvRare /* read through rare_args(), never by name */
                      const uint32_t* __restrict__ safe_chunks /* null with a separator mask: every chunk then tests every two steps */,
                      const int64_t nsymbols, const uint32_t nrows_padded) {
     ssv_diag_body<false>(seq, rows, safe_chunks, nsymbols, nrows_padded);
+}
+
+// the same body for launches of short items (see "the short-model variant"): five waves per SIMD, loads a tile ahead
+__global__ __launch_bounds__(64 * kWavesPerBlock, 5)
+void ssv_diag_kernel_short(const SsvRare, const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
+                           const uint32_t* __restrict__ safe_chunks, const int64_t nsymbols, const uint32_t nrows_padded) {
+    ssv_diag_body<false, true>(seq, rows, safe_chunks, nsymbols, nrows_padded);
 }
 
 // the same body with the per-cell trace compiled in (see CellRecord): a debugging aid, never launched unless a trace window is set

@@ -225,6 +225,8 @@ class ShardedSsv:
                 slot.ctx.set_tuning(*tuning[:4])
                 if len(tuning) > 4:
                     slot.ctx.set_split_tuning(*tuning[4:8])
+                if len(tuning) > 8:
+                    slot.ctx.set_kernel_variant(tuning[8])
         _low, high = torch.cuda.Stream.priority_range()
         self.kernel_stream = torch.cuda.Stream(device, priority=high) if depth > 1 else None
         self.in_flight = []               # slot indices, oldest first

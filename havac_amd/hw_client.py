@@ -84,7 +84,7 @@ class HavacHwClient:
 
     def setTuning(self, *values: int):
         """experiment knobs (include/havac_dev.h: havac_dev_set_tuning): rows_per_block, tiles_per_item, block_tails, ordering,
-        parts_log2, split_rounds_x4, short_rows, guide; -1 or missing = the library's own rule"""
+        parts_log2, split_rounds_x4, short_rows, guide, kernel variant (0 standard, 1 short-model); -1 or missing = the library's own rule"""
         import ctypes
         arr = (ctypes.c_int32 * len(values))(*[int(v) for v in values])
         self._check(self._L.havac_dev_set_tuning(self._h, arr, len(values)))

@@ -72,6 +72,16 @@ class SsvContext:
         """the library's rule for tall tiles (include/havac_dev.h: havac_ssv_set_split_tuning); -1 = the default"""
         self._check(self._L.havac_ssv_set_split_tuning(self._h, parts_log2, split_rounds_x4, short_rows, guide))
 
+    def set_kernel_variant(self, variant: int = -1):
+        """which instantiation of the SSV kernel the next passes run (include/havac_dev.h: havac_ssv_set_kernel_variant):
+        -1 the library decides, 0 the standard kernel, 1 the short-model kernel wherever it is valid"""
+        self._check(self._L.havac_ssv_set_kernel_variant(self._h, variant))
+
+    def last_kernel_variant(self) -> int:
+        v = C.c_int(0)
+        self._check(self._L.havac_ssv_last_kernel_variant(self._h, C.byref(v)))
+        return v.value
+
     def wave_slots(self) -> int:
         """waves the context's device holds at once: what enqueue() hands to the planner (launch_plan(wave_slots=...))"""
         n = C.c_uint32(0)
@@ -148,7 +158,7 @@ class _LaunchPlan(C.Structure):
                 ("nparts", C.c_uint32), ("part_begin", C.c_uint32 * 9),
                 ("tiles_per_group", C.c_uint32), ("single_tiles", C.c_uint32), ("cut_tiles", C.c_uint32),
                 ("nrow_blocks", C.c_uint32), ("ncuts", C.c_uint32), ("uniform_rows", C.c_uint32), ("row_cut", C.c_uint32 * 33),
-                ("workgroups", C.c_uint32)]
+                ("workgroups", C.c_uint32), ("short_kernel", C.c_uint32)]
 
 
 def launch_plan(nsymbols: int, nrows: int, shard_index: int = 0, shard_count: int = 1, wave_slots: int = 0, tuning=()):

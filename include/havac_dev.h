@@ -100,8 +100,9 @@ void havac_dev_destroy(havac_dev *dev);
 
 /* Change the hit-buffer capacity (records). */
 int havac_dev_set_hit_capacity(havac_dev *dev, uint64_t max_hits);
-/* Experiment knobs of the handle's runs: up to eight values, in the order of havac_ssv_set_tuning's and then
- * havac_ssv_set_split_tuning's arguments (see there; missing values and -1 = the library's own rule).  Applies to every
+/* Experiment knobs of the handle's runs: up to nine values, in the order of havac_ssv_set_tuning's, then
+ * havac_ssv_set_split_tuning's arguments, then havac_ssv_set_kernel_variant's (see there; missing values and -1 = the library's
+ * own rule).  Applies to every
  * GPU of the handle.  No counterpart in the reference. */
 int havac_dev_set_tuning(havac_dev *dev, const int32_t *values, uint32_t count);
 
@@ -297,9 +298,19 @@ int havac_ssv_set_tuning(havac_ssv_ctx *ctx, int rows_per_block, int tiles_per_i
  *   guide            a row block takes 1 / guide of the rows that are left (2 ... 16; default 2) */
 int havac_ssv_set_split_tuning(havac_ssv_ctx *ctx, int parts_log2, int split_rounds_x4, int short_rows, int guide);
 
+/* Which instantiation of the SSV kernel the next passes run.  -1 (the default): the library decides -- models of up to 128 rows
+ * (a tile is one to four 32-row chunks and mostly prologue) take the short-model kernel: five waves per SIMD, every wave walks a
+ * group of adjacent tiles with the next tile's first loads in flight across the current one; everything else, and every pass
+ * with a separator mask or a cell trace, the standard kernel.  0: always the standard kernel; 1: the short-model kernel wherever
+ * it is valid (A/B, tests).  The records are the same either way.  The reference's array runs at the same efficiency whatever
+ * the model's height (README.md:4; device/HavacHls.cpp:220-319): this is what keeps short models near that.
+ * havac_ssv_last_kernel_variant: what the last enqueued pass ran (0 standard, 1 short). */
+int havac_ssv_set_kernel_variant(havac_ssv_ctx *ctx, int variant);
+int havac_ssv_last_kernel_variant(havac_ssv_ctx *ctx, int *variant);
+
 /* How a launch of this shape would hand out its tiles (the same planner havac_ssv_enqueue uses; no device is touched, so
  * tests and tools can look at a plan anywhere).  `wave_slots`: waves the device holds at once (0 = an MI355X: 256 CUs x 24);
- * `tuning`: up to eight values as for havac_dev_set_tuning (NULL / -1 = the library's own rule).
+ * `tuning`: up to nine values as for havac_dev_set_tuning (NULL / -1 = the library's own rule).
  *   partitions      nparts runs of adjacent tiles of about equal work: partition k = tiles [part_begin[k], part_begin[k+1])
  *                   of the launch's ntiles tiles; workgroup i serves partition i mod nparts
  *   a partition's items, in this order: groups of tiles_per_group adjacent tiles (a wave walks a group; short models), single
@@ -314,6 +325,7 @@ typedef struct havac_launch_plan {
     uint32_t tiles_per_group, single_tiles, cut_tiles;
     uint32_t nrow_blocks, ncuts, uniform_rows, row_cut[33];
     uint32_t workgroups;
+    uint32_t short_kernel;   /* 1: the launch runs the short-model instantiation of the kernel (havac_ssv_set_kernel_variant) */
 } havac_launch_plan;
 int havac_ssv_plan(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index, uint32_t shard_count, uint32_t wave_slots,
                    const int32_t *tuning, uint32_t ntuning, havac_launch_plan *plan_out);

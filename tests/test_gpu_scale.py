@@ -14,13 +14,16 @@ def torch_dev():
     return torch, torch.device("cuda", 0)
 
 
-def run_shards(torch, dev, packed, model, world=1, capacity=1 << 22, tuning=None, orderings=None):
+def run_shards(torch, dev, packed, model, world=1, capacity=1 << 22, tuning=None, orderings=None, variant=None, variants_run=None):
     """-> list of per-shard device-ordered record arrays (numpy uint64); `tuning` = keyword arguments of
-    SsvContext.set_tuning; `orderings` (a list) receives last_ordering() of every shard's pass"""
+    SsvContext.set_tuning; `orderings` (a list) receives last_ordering() of every shard's pass; `variant`: the kernel
+    instantiation to force (SsvContext.set_kernel_variant), `variants_run` (a list) receives what every pass ran"""
     from havac_amd.ssv import SsvContext
     ctx = SsvContext()
     if tuning:
         ctx.set_tuning(**tuning)
+    if variant is not None:
+        ctx.set_kernel_variant(variant)
     d_seq = torch.from_numpy(packed).to(dev)
     d_phmm = torch.from_numpy(np.ascontiguousarray(model).reshape(-1)).to(dev)
     hits = torch.empty(capacity, dtype=torch.int64, device=dev)
@@ -32,6 +35,8 @@ def run_shards(torch, dev, packed, model, world=1, capacity=1 << 22, tuning=None
         out.append(hits[:n].cpu().numpy().view(np.uint64).copy())
         if orderings is not None:
             orderings.append(ctx.last_ordering())
+        if variants_run is not None:
+            variants_run.append(ctx.last_kernel_variant())
     ctx.close()
     return out
 
@@ -323,14 +328,55 @@ def test_short_models_whole_hit_list(torch_dev, oracle, nrows):
     ncols = 100_012_032
     model, cons = synth.dfam_like_model(nrows, 4242 + nrows)
     packed = synth.random_packed(ncols, 4243)
-    got, = run_shards(torch, dev, packed, model)
+    ran = []
+    got, = run_shards(torch, dev, packed, model, variants_run=ran)
+    assert ran == [1]                    # the short-model kernel (round 4): five waves per SIMD, walks of four tiles, loads a tile ahead
     assert got.size > 1000
     want = whole_list(oracle, packed, model)
     assert np.array_equal(got, want)
+    # the standard kernel on the same problem (single tiles), and the standard kernel walking groups of four
+    again, = run_shards(torch, dev, packed, model, variant=0, variants_run=ran)
+    assert ran[-1] == 0 and np.array_equal(again, want)
     if nrows == 64:
-        # the experiment's item order: groups of four adjacent tiles per wave, a partition's last round of wave slots as single tiles
-        again, = run_shards(torch, dev, packed, model, tuning=dict(tiles_per_item=-4))
+        again, = run_shards(torch, dev, packed, model, tuning=dict(tiles_per_item=-4), variant=0)
         assert np.array_equal(again, want)
+        # the short-model kernel with other walks: every tile a walk of its own (loads never ahead), long walks without single tiles
+        for walk in (1, 2, 7, -3):
+            again, = run_shards(torch, dev, packed, model, tuning=dict(tiles_per_item=walk), variant=1, variants_run=ran)
+            assert ran[-1] == 1 and np.array_equal(again, want), walk
+
+
+def test_short_model_kernel_on_small_ragged_problems(torch_dev, oracle):
+    """ssv_diag_kernel_short where its prefetch meets the matrix's edges: a handful of tiles (the first tile's diagonals start
+    left of column 0, the last one's end right of column N), one-row and 128-row models, tile counts that are no multiple of the
+    walk, dense-hit models (two-step windows), sharded runs (every shard walks its own tiles), and the cases it must NOT
+    take: 129 rows, a separator mask (boundary mode) -- the library's choice falls back to the standard kernel."""
+    torch, dev = torch_dev
+    rng = np.random.default_rng(404)
+    for case in range(24):
+        nrows = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 96, 100, 127, 128]))
+        nseg = int(rng.integers(1, 9))
+        sym = synth.random_symbols(nseg * synth.SEGMENT, 150 + case)
+        if case % 4 == 0:
+            model = rng.integers(-128, 128, size=(nrows, 4)).astype(np.int8)
+        else:
+            model, cons = synth.dfam_like_model(nrows, 160 + case)
+            synth.plant_homologs(sym, cons, sym.size, every=700, length=min(nrows, 150), sub=0.08)
+        walk = int(rng.choice([-1, 1, 2, 3, 4, 8, -2, -4]))
+        ran = []
+        got, = run_shards(torch, dev, synth.pack_2bit(sym), model, capacity=1 << 23, tuning=dict(tiles_per_item=walk), variant=1, variants_run=ran)
+        want = oracle.ssv(sym, model, cap=1 << 23)
+        assert ran == [1] and np.array_equal(got, want), (case, nrows, nseg, walk, got.size, want.size)
+    sym = synth.random_symbols(11 * synth.SEGMENT, 199)
+    model, cons = synth.dfam_like_model(96, 198)
+    synth.plant_homologs(sym, cons, sym.size, every=700, length=60, sub=0.05)
+    ran = []
+    parts = run_shards(torch, dev, synth.pack_2bit(sym), model, world=4, variants_run=ran)
+    assert ran == [1, 1, 1, 1] and np.array_equal(np.concatenate(parts), oracle.ssv(sym, model))
+    model129, _ = synth.dfam_like_model(129, 197)
+    ran = []
+    got, = run_shards(torch, dev, synth.pack_2bit(sym), model129, variant=1, variants_run=ran)
+    assert ran == [0] and np.array_equal(got, oracle.ssv(sym, model129))
 
 
 @pytest.mark.parametrize("per_item", [2, 3, 8])

@@ -21,7 +21,7 @@ SHAPES = [  # (columns, rows, shard, shards)
     (40 * SEG, 65_500, 1, 3),
     (400 * SEG, 9_000, 0, 1),
 ]
-TUNINGS = [(), (-1, -1, -1, -1, 3, 1, 1024, 2), (-1, -1, -1, -1, 0, 64, 2048, 3), (4096, -1, -1, -1, 3), (0,), (-1, 3), (-1, 8, -1, -1, 2), (-1, -4),
+TUNINGS = [(), (-1, -1, -1, -1, -1, -1, -1, -1, 0), (-1, 2, -1, -1, -1, -1, -1, -1, 1), (-1, -1, -1, -1, 3, 1, 1024, 2), (-1, -1, -1, -1, 0, 64, 2048, 3), (4096, -1, -1, -1, 3), (0,), (-1, 3), (-1, 8, -1, -1, 2), (-1, -4),
            (-1, -1, -1, -1, 3, 6, 1024, 16)]
 
 
@@ -73,11 +73,18 @@ def test_the_rules_on_the_baseline_shapes():
     assert sizes[0] > sizes[3] * 1.15 and sizes[-1] > sizes[3] * 1.15                              # partitions of equal work: the two ends hold more (shorter) tiles
     c5 = launch_plan(100_012_032, 20_000)
     assert c5["row_blocks"] == [(0, 10240), (10240, 15360), (15360, 20000)] and c5["cut_tiles"] == 1152    # 1.5 rounds of 6144 slots over 8 partitions
+    # short models (round 4): the short-model kernel -- five waves per SIMD, 5120 wave slots -- walks groups of four tiles, a
+    # partition's last round of wave slots as single tiles; the standard kernel (variant 0) keeps single tiles
     short = launch_plan(100_012_032, 32)
-    assert short["tiles_per_group"] == 1 and short["nrow_blocks"] == 1                            # single tiles (groups are an experiment)
-    walk = launch_plan(100_012_032, 32, tuning=(-1, -4))
+    assert short["short_kernel"] == 1 and short["tiles_per_group"] == 4 and short["single_tiles"] == 640 and short["nrow_blocks"] == 1
+    assert all(sum(1 for _, w, _ in p if w == 1) >= 640 and sum(1 for _, w, _ in p if w == 4) > 1000 for p in short["items"])
+    assert launch_plan(100_012_032, 128)["short_kernel"] == 1 and launch_plan(100_012_032, 129)["short_kernel"] == 0
+    std = launch_plan(100_012_032, 32, tuning=(-1, -1, -1, -1, -1, -1, -1, -1, 0))
+    assert std["short_kernel"] == 0 and std["tiles_per_group"] == 1 and std["nrow_blocks"] == 1
+    walk = launch_plan(100_012_032, 32, tuning=(-1, -4, -1, -1, -1, -1, -1, -1, 0))
     assert walk["tiles_per_group"] == 4 and walk["single_tiles"] == 768
     assert all(sum(1 for _, w, _ in p if w == 1) >= 768 and sum(1 for _, w, _ in p if w == 4) > 1000 for p in walk["items"])
+    assert c2["short_kernel"] == 0 and c5["short_kernel"] == 0
 
 
 def test_refusals():

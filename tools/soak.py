@@ -55,7 +55,12 @@ for case in range(cases):
     use_mask = rng.random() < 0.3
     # how the launch hands out its tiles (havac_dev_set_tuning): the library's own rule half of the time, else a random one --
     # partitions or none, how many of the last tiles are cut, finest block, taper; or uniform row blocks for every tile
-    tuning = [-1] * 8
+    tuning = [-1] * 9
+    # which instantiation of the kernel (round 4): the library's choice, or forced -- short models then run the standard kernel,
+    # or the short-model kernel with a random walk length (groups of g tiles; negative: the last round of wave slots single)
+    tuning[8] = int(rng.choice([-1, -1, 0, 1]))
+    if nrows <= 128 and rng.random() < 0.5:
+        tuning[1] = int(rng.choice([1, 2, 3, 5, 8, -2, -4, -7]))
     pick = rng.random()
     if pick < 0.35:
         tuning[4:8] = [int(rng.choice([0, 1, 2, 3])), int(rng.choice([0, 1, 2, 6, 64])), int(rng.choice([1024, 2048, 4096])), int(rng.choice([2, 3, 4, 16]))]
