@@ -312,7 +312,10 @@ def describe_plan(ncols, nrows, rank, world, tuning, wave_slots=0):
     t = [t[0] if len(t) > 0 else -1, t[1] if len(t) > 1 else -1, -1, -1] + (t[4:9] if len(t) > 4 else [])
     p = launch_plan(ncols, nrows, rank, world, wave_slots=wave_slots, tuning=t)
     cut = p["cut_tiles"] if p["nrow_blocks"] > 1 else 0
-    return {"kernel": "ssv_diag_kernel_short (5 waves per SIMD, walks of tiles, loads a tile ahead)" if p["short_kernel"] else "ssv_diag_kernel",
+    if p["resident_kernel"]:
+        return {"kernel": "ssv_resident_kernel (tables resident in LDS, every wave walks its run of tiles)", "wave_slots": wave_slots or 256 * 24,
+                "tiles": p["ntiles"], "workgroups": p["workgroups"], "waves_per_round": p["walk_slots"], "tiles_per_wave_by_round": p["walk_len"]}
+    return {"kernel": "ssv_diag_kernel",
             "tiles_per_walk": p["tiles_per_group"], "wave_slots": wave_slots or 256 * 24, "tiles": p["ntiles"], "partitions": p["nparts"], "workgroups": p["workgroups"],
             "cut_tiles_per_partition": "all" if cut >= max(b - a for a, b in zip(p["part_begin"], p["part_begin"][1:])) and cut else cut,
             "row_blocks_per_cut_tile": p["nrow_blocks"] if cut else 0,
@@ -613,7 +616,7 @@ def main():
                 "baseline": "1739 GCUPS = reference README.md:4, 1x Alveo U50 FPGA",
                 "work_distribution": describe_plan(ncols, nrows, rank, world, tuning, wave_slots),
             },
-            "kernel": {"name": "ssv_diag_kernel_short" if engine_variant else "ssv_diag_kernel", "avg_ms": round(ssv_ms, 4), "enqueue_to_ordered_ms": round(enq_ms, 4),
+            "kernel": {"name": "ssv_resident_kernel" if engine_variant else "ssv_diag_kernel", "avg_ms": round(ssv_ms, 4), "enqueue_to_ordered_ms": round(enq_ms, 4),
                        "gcups_kernel_only": round(my_cells / kernel_s / 1e9, 1)},
             "roofline": {
                 "bound": "valu", "achieved": round(achieved_tiops, 2), "peak": PEAK_TIOPS_I16,

@@ -161,27 +161,60 @@ RowCuts plan_row_cuts(uint32_t nrows_padded, uint32_t short_rows, uint32_t guide
 //    everywhere at about the same time.  Round 2 cut EVERY tile into blocks of 8192 rows: the same balance, but a hand-off per
 //    8192 x 2048 cells was 7-9 x the bytes the problem needs on C3 and C5.  (Cutting SHORT tiles to fill the last round -- C2
 //    is 9.54 rounds -- does not pay: 2, 3, 4 row blocks per 1024-row tile took 2.20, 3.22, 4.5 ms against 2.02.);
-//  * short models (at most kShortItemRows rows: a tile is one to four chunks and mostly prologue) take the second instantiation
-//    of the kernel, ssv_diag_kernel_short: five waves per SIMD, every wave walks a group of kShortWalk adjacent tiles with the
-//    next tile's first loads in flight across the current one (ssv_kernels.hip.h, "the short-model variant"); a partition's last
-//    round of wave slots stays single tiles, so that the launch still ends evenly.
-constexpr int kShortWalk = 4;
+//  * short models (at most kResidentRows rows: a tile is one to eight chunks and, handed out tile by tile, mostly prologue) take
+//    ssv_resident_kernel: as many workgroups as the chip holds at once, the model's tables built once per workgroup and kept
+//    in LDS, every wave walks its own run of adjacent tiles -- runs of equal length (+- one tile), dealt by the wave's number
+//    alone (ssv_kernels.hip.h, "the resident-table variant").  No partitions, no tickets, no cut tiles, no block tails.
+constexpr uint64_t kWalkShareX16 = 9;      // resident-table launches: a round's runs take 9/16 of the tiles that are left per wave slot
 struct PlanTuning { int rows_per_block, tiles_per_item, parts_log2; uint32_t split_rounds_x4, short_rows, guide; int variant = -1; };
-struct LaunchPlan { SsvRare L{}; uint32_t nblocks = 0, largest_item_rows = 0; bool short_kernel = false; };
-// which instantiation runs a launch: the short-model one where the model is short and nothing it leaves out is asked for
-// (separator masks, the per-cell trace, row blocks); `variant`: -1 = this rule, 0 = always the standard kernel, 1 = the short
-// one wherever it is valid (tests, A/B)
-bool pick_short_kernel(const Tiling& t, int variant, bool has_mask, bool has_trace) {
-    return variant != 0 && !has_mask && !has_trace && t.nrows_padded <= kShortItemRows;
+struct LaunchPlan { SsvRare L{}; uint32_t nblocks = 0, largest_item_rows = 0; bool resident_kernel = false; };
+// which kernel runs a launch: the resident-table one where the model is short and nothing it leaves out is asked for (separator
+// masks, the per-cell trace, a forced work distribution); `variant`: -1 = this rule, 0 = always the standard kernel, 1 = the
+// resident-table one wherever it is valid (tests, A/B)
+bool pick_resident_kernel(const Tiling& t, const PlanTuning& tune, bool has_mask, bool has_trace) {
+    if (tune.variant == 0 || has_mask || has_trace || t.nrows_padded > kResidentRows) return false;
+    return tune.variant == 1 || (tune.rows_per_block < 0 && tune.tiles_per_item == -1);
 }
 int plan_launch(std::string& err, const Tiling& t, uint32_t tb, uint32_t te, int64_t col_end, uint64_t slots, const PlanTuning& tune,
                 const uint32_t* known_part_begin /* 9 entries of an earlier plan of the same shape, or null */, LaunchPlan& plan,
-                bool short_kernel = false) {
+                bool resident_kernel = false) {
     SsvRare& L = plan.L;
-    plan.short_kernel = short_kernel;
-    if (short_kernel) slots = slots * 5 / 6;          // five waves per SIMD instead of six
+    plan.resident_kernel = resident_kernel;
     L.first_diag = t.first_diag; L.tile_begin = tb; L.ntiles = te - tb;
     L.col_end = col_end;
+    if (resident_kernel) {
+        // Runs of adjacent tiles, handed out in ROUNDS of as many waves as the device holds (guided self-scheduling: the hardware
+        // starts a round's workgroups as the slots of the round before come free).  A SIMD serves its oldest wave first, so the
+        // waves of a round do not end together but one after the other; equal runs in ONE round left the SIMDs with five, four,
+        // ... one wave over the last 60 % of the launch (50 TCUPS at 256 rows where single tiles run at 56).  So the runs taper:
+        // a round takes kWalkShare of what is left per slot, the last rounds are single tiles -- a workgroup's start, its tables
+        // and its end are paid ~3 times per slot instead of once per tile, and the launch still ends within a tile's time.
+        // (tests: tiles_per_item = G >= 1 asks for runs of G tiles throughout, so that small problems walk too)
+        const uint64_t nslots = std::max<uint64_t>(kWavesPerBlock, slots / kWavesPerBlock * kWavesPerBlock);
+        L.parts_log2 = 0;
+        for (uint32_t k = 0; k <= 8; k++) L.part_begin[k] = k ? L.ntiles : 0u;
+        L.tiles_per_item = 1; L.single_tiles = 0; L.split_units = 0; L.nrow_blocks = 1;
+        L.walk_slots = (uint32_t)nslots;
+        uint64_t at = 0, nwaves = 0;
+        uint32_t r = 0;
+        for (; r < (uint32_t)kMaxWalkRounds && at < L.ntiles; r++) {
+            const uint64_t left = L.ntiles - at;
+            uint64_t len = tune.tiles_per_item >= 1 ? (uint64_t)tune.tiles_per_item : std::max<uint64_t>(1, left * kWalkShareX16 / (16 * nslots));
+            if (r + 1 == (uint32_t)kMaxWalkRounds && tune.tiles_per_item < 1) len = std::max<uint64_t>(len, (left + nslots - 1) / nslots);   // (never reached in practice: the table's last round takes all that is left)
+            L.walk_len[r] = (uint32_t)len; L.walk_base[r] = (uint32_t)at;
+            const uint64_t want = (left + len - 1) / len;                      // waves that would finish the launch at this length
+            const bool final_round = want <= nslots || len == 1 || tune.tiles_per_item >= 1 || r + 1 == (uint32_t)kMaxWalkRounds;
+            const uint64_t waves = final_round ? (want + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock : nslots;
+            nwaves += waves;
+            at += waves * len;
+            if (final_round) { r++; break; }
+        }
+        L.walk_rounds = std::max(1u, r);
+        if (nwaves * 64 >= (1ull << 32)) { err = "too many tiles for one launch of runs of " + std::to_string(L.walk_len[0]) + " tiles"; return HAVAC_E_LENGTH; }
+        plan.nblocks = L.ntiles ? (uint32_t)(nwaves / kWavesPerBlock) : 0u;
+        plan.largest_item_rows = t.nrows_padded;
+        return HAVAC_OK;
+    }
     L.parts_log2 = L.ntiles >= 64 ? 3u : 0u;
     if (tune.parts_log2 >= 0) L.parts_log2 = (uint32_t)tune.parts_log2;
     const uint32_t nparts = 1u << L.parts_log2;
@@ -217,7 +250,7 @@ int plan_launch(std::string& err, const Tiling& t, uint32_t tb, uint32_t te, int
     // 10 %, with or without the next tile's symbols fetched a tile ahead.  tiles_per_item = G > 1: every tile in a
     // group; G < -1: groups of -G tiles, but a partition's last round of wave slots as single tiles.
     uint32_t tiles_per_item = 1, single_tiles = 0;
-    const int walk = tune.tiles_per_item == -1 && short_kernel ? -kShortWalk : tune.tiles_per_item;      // (the short kernel's default: groups, the last round single)
+    const int walk = tune.tiles_per_item;
     if (walk >= 1 && !split) tiles_per_item = (uint32_t)walk;
     if (walk < -1 && !split) { tiles_per_item = (uint32_t)(-walk); single_tiles = (uint32_t)((slots + nparts - 1) / nparts); }
     L.tiles_per_item = tiles_per_item; L.single_tiles = single_tiles;
@@ -306,8 +339,8 @@ struct havac_ssv_ctx {
     uint64_t window_first = 0, window_columns = 0;   // the caller's sequence buffer holds only these columns (0, 0: all of them)
     // experiment knobs (havac_ssv_set_tuning): -1 = the library decides
     int tune_rows_per_block = -1, tune_tiles_per_item = -1, tune_block_tails = -1;
-    int tune_variant = -1;                     // havac_ssv_set_kernel_variant: -1 the library decides, 0 standard kernel, 1 short-model kernel where valid
-    bool last_short_kernel = false;
+    int tune_variant = -1;                     // havac_ssv_set_kernel_variant: -1 the library decides, 0 standard kernel, 1 resident-table kernel where valid
+    bool last_resident_kernel = false;
     // havac_ssv_set_split_tuning: partitions (-1: the library decides), rounds of wave slots whose tiles are cut (x4), finest row block, taper
     PartitionKey part_key{}; uint32_t part_begin[9] = {};            // the partitions of the last launch's shape (plan_partitions)
     uint32_t last_plan_blocks = 0, last_plan_item_rows = 0;
@@ -323,6 +356,11 @@ struct havac_ssv_ctx {
     std::string err;
 };
 
+#ifdef HAVAC_WAVE_CLOCKS
+extern "C" int havac_debug_wave_clocks(uint64_t* out, uint32_t nwaves) {      // experiments only: see g_wave_clocks
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_clocks), (size_t)nwaves * 4 * sizeof(uint64_t)) == hipSuccess ? 0 : 1;
+}
+#endif
 extern "C" const char* havac_dev_version(void) { return "havac_dev 0.1 gfx950"; }
 
 extern "C" int havac_ssv_ctx_create(havac_ssv_ctx** out) {
@@ -476,7 +514,7 @@ extern "C" int havac_ssv_plan(uint64_t nsymbols, uint32_t nrows, uint32_t shard_
     shard_tiles(t, nrows, col_begin, col_end, &tb, &te);
     LaunchPlan plan;
     if (int rc = plan_launch(err, t, tb, te, (int64_t)col_end, wave_slots ? wave_slots : 256u * kBlocksPerCu * kWavesPerBlock, tune, nullptr, plan,
-                             pick_short_kernel(t, tune.variant, false, false))) return rc;
+                             pick_resident_kernel(t, tune, false, false))) return rc;
     const SsvRare& L = plan.L;
     std::memset(out, 0, sizeof(*out));
     out->nrows_padded = t.nrows_padded; out->tile_begin = L.tile_begin; out->ntiles = L.ntiles;
@@ -486,21 +524,23 @@ extern "C" int havac_ssv_plan(uint64_t nsymbols, uint32_t nrows, uint32_t shard_
     out->nrow_blocks = L.ntiles ? L.nrow_blocks : 0; out->ncuts = L.ncuts; out->uniform_rows = L.uniform_rows;
     for (uint32_t i = 0; i <= (uint32_t)kMaxRowCuts; i++) out->row_cut[i] = L.row_cut[i];
     out->workgroups = plan.nblocks;
-    out->short_kernel = plan.short_kernel ? 1u : 0u;
+    out->resident_kernel = plan.resident_kernel ? 1u : 0u;
+    out->walk_slots = L.walk_slots; out->walk_rounds = L.walk_rounds;
+    for (int r = 0; r < kMaxWalkRounds; r++) { out->walk_len[r] = L.walk_len[r]; out->walk_base[r] = L.walk_base[r]; }
     return HAVAC_OK;
 }
 
 extern "C" int havac_ssv_set_kernel_variant(havac_ssv_ctx* c, int variant) {
     if (!c) return HAVAC_E_ARGUMENT;
     if (c->pending) { c->err = "a pass is in flight: change the kernel variant between passes"; return HAVAC_E_LOGIC; }
-    if (variant > 1) { c->err = "kernel variant: -1 (the library decides), 0 (standard) or 1 (short models)"; return HAVAC_E_ARGUMENT; }
+    if (variant > 1) { c->err = "kernel variant: -1 (the library decides), 0 (standard) or 1 (resident tables: short models)"; return HAVAC_E_ARGUMENT; }
     c->tune_variant = variant < 0 ? -1 : variant;
     return HAVAC_OK;
 }
 
 extern "C" int havac_ssv_last_kernel_variant(havac_ssv_ctx* c, int* variant) {
     if (!c || !variant) return HAVAC_E_ARGUMENT;
-    *variant = c->last_short_kernel ? 1 : 0;
+    *variant = c->last_resident_kernel ? 1 : 0;
     return HAVAC_OK;
 }
 
@@ -610,14 +650,14 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     SsvRare L{};          // the kernel's first argument: tiling, hit queue, hand-off buffers (read from the kernarg segment on demand)
     const uint64_t slots = (uint64_t)c->resident_blocks * kWavesPerBlock;
     const PlanTuning tuning{c->tune_rows_per_block, c->tune_tiles_per_item, c->tune_parts_log2, c->tune_split_rounds_x4, c->tune_short_rows, c->tune_guide, c->tune_variant};
-    const bool short_kernel = pick_short_kernel(t, c->tune_variant, c->pair_mask != nullptr, c->trace_cells != nullptr);
+    const bool resident_kernel = pick_resident_kernel(t, tuning, c->pair_mask != nullptr, c->trace_cells != nullptr);
     {
         // (the partitions are kept from pass to pass while the shape stays the same: a pass of C2 is 1.9 ms, the table takes 50,000 tiles)
         const PartitionKey key{nsymbols, nrows, col_begin, col_end, tb, te, (uint32_t)c->tune_parts_log2};
         const bool cached = key == c->part_key;
         LaunchPlan plan;
-        if (int prc = plan_launch(c->err, t, tb, te, (int64_t)col_end, slots, tuning, cached ? c->part_begin : nullptr, plan, short_kernel)) return prc;
-        if (!cached) { for (uint32_t k = 0; k <= 8; k++) c->part_begin[k] = plan.L.part_begin[k]; c->part_key = key; }
+        if (int prc = plan_launch(c->err, t, tb, te, (int64_t)col_end, slots, tuning, cached && !resident_kernel ? c->part_begin : nullptr, plan, resident_kernel)) return prc;
+        if (!cached && !resident_kernel) { for (uint32_t k = 0; k <= 8; k++) c->part_begin[k] = plan.L.part_begin[k]; c->part_key = key; }
         L = plan.L;
         c->last_plan_blocks = plan.nblocks; c->last_plan_item_rows = plan.largest_item_rows;
     }
@@ -673,12 +713,12 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         R.cells = c->trace_cells; R.cell_row0 = c->trace_row0; R.cell_col0 = (int64_t)c->trace_col0;
         R.cell_rows = c->trace_rows; R.cell_cols = c->trace_cols;
         const uint32_t* const safe_chunks = c->pair_mask ? (const uint32_t*)nullptr : (const uint32_t*)c->chunk_flags;
-        c->last_short_kernel = short_kernel;
+        c->last_resident_kernel = resident_kernel;
         if (c->trace_cells)       // debugging: the same kernel body with the per-cell trace compiled in
             hipLaunchKernelGGL(ssv_diag_kernel_traced, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,
                                d_sequence, (const uint32_t*)c->rows8, safe_chunks, (int64_t)nsymbols, t.nrows_padded);
-        else if (short_kernel)    // short models: five waves per SIMD, walks of tiles with their first loads a tile ahead
-            hipLaunchKernelGGL(ssv_diag_kernel_short, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,
+        else if (resident_kernel)    // short models: the chip's worth of workgroups, tables resident in LDS, every wave walks its run of tiles
+            hipLaunchKernelGGL(ssv_resident_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,
                                d_sequence, (const uint32_t*)c->rows8, safe_chunks, (int64_t)nsymbols, t.nrows_padded);
         else
             hipLaunchKernelGGL(ssv_diag_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,

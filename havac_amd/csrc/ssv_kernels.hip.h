@@ -104,6 +104,7 @@ constexpr uint32_t kOutsideReset = 0x80008000u;   // match word "score -128" for
 constexpr uint32_t kOutsideNeutral = 0u;          // match word "score 0": columns outside the matrix when there are no separators
 constexpr uint32_t kPadRow = 0u;                  // a row outside the model scores 0 for every symbol: it changes nothing and can never hit
 constexpr int kMaxRowCuts = 32;                   // row blocks of individual height in front of the uniform ones (SsvRare::row_cut)
+constexpr int kMaxWalkRounds = 8;                 // rounds of runs of a resident-table launch (SsvRare::walk_len)
 constexpr int kWindowSteps = 4;                   // steps between two hit tests where the model allows it (ssv_prepare_model)
 
 // per-wave LDS: 16 step-pair tables of 17 entries x 8 B, the record stage
@@ -365,6 +366,9 @@ struct SsvRare {
     uint32_t part_begin[9];        // partition k owns tiles [part_begin[k], part_begin[k+1]) of the launch: runs of about equal WORK (tiles at the matrix's ends are short)
     uint32_t tiles_per_item;       // >= 1; > 1 (experiments, short models): a wave walks a GROUP of that many adjacent tiles
     uint32_t single_tiles;         // ... except a partition's last single_tiles whole tiles, which are items of their own (the launch's last round)
+    // ssv_resident_kernel: the launch's waves come in walk_rounds rounds of walk_slots waves (the last round: as many as it takes);
+    // wave i of round r walks walk_len[r] adjacent tiles from tile walk_base[r] + i * walk_len[r] on (clipped to the launch's tiles)
+    uint32_t walk_slots, walk_rounds, walk_len[kMaxWalkRounds], walk_base[kMaxWalkRounds];
     uint32_t split_units;          // of every partition's units the LAST split_units are cut by rows (0: no tile of this launch is cut)
     uint32_t nrow_blocks;          // row blocks of a cut tile
     uint32_t ncuts, uniform_rows;  // block b < ncuts is rows [row_cut[b], row_cut[b+1]); from block ncuts on the blocks are uniform_rows rows each
@@ -385,7 +389,7 @@ __device__ __forceinline__ rare_args_t rare_args() {
 }
 
 struct HitSink {
-    WaveLds* lds;
+    uint64_t* stage;               // the wave's kHitStage staged records (LDS)
 };
 
 // A staged record is (row << 40 | column): two scalar instructions in the slow path; the sort key (a division by
@@ -408,7 +412,7 @@ __device__ __forceinline__ uint32_t flush_hits(const HitSink& sink, const rare_a
     base = ((unsigned long long)hi << 32) | lo;
     for (uint32_t i = lane; i < staged; i += 64) {
         const unsigned long long idx = base + i;
-        if (idx < capacity) hits[idx] = staged_to_key(sink.lds->stage[i], row_bits);
+        if (idx < capacity) hits[idx] = staged_to_key(sink.stage[i], row_bits);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     return 0;
@@ -437,7 +441,7 @@ __device__ __forceinline__ uint32_t emit_cell(const HitSink& sink, const ShardCo
     const rare_args_t rare = own.rare;
     if ((uint64_t)(column - own.begin) < own.span) {
         const uint64_t record = ((uint64_t)row << 40) | (uint64_t)column;
-        const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint64_t*)sink.lds->stage + staged * 8;
+        const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint64_t*)sink.stage + staged * 8;
         uint64_t saved_exec;        // one lane stores: exec = lane 0 for the one instruction
         asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b64 %1, %2\n\ts_mov_b64 exec, %0"
                      : "=&s"(saved_exec) : "v"(addr), "v"(record) : "memory");
@@ -449,9 +453,15 @@ __device__ __forceinline__ uint32_t emit_cell(const HitSink& sink, const ShardCo
 
 // both steps' match words of one register: one ds_read_b64, table of step pair P, entry `code_addr`
 template <int P>
-__device__ __forceinline__ u32x2 match_words(uint32_t code_addr) {
-    return *(lds_words_t)(uintptr_t)(code_addr + P * kPairStride);
+__device__ __forceinline__ u32x2 match_words(uint32_t code_addr, int extra = 0) {
+    return *(lds_words_t)(uintptr_t)(code_addr + P * kPairStride + extra);
 }
+// Resident tables (ssv_resident_body: every chunk of a short model has its own table in LDS, kTableBytes apart, built once per
+// workgroup).  A window entry carries the base of the table of the chunk it was EXPANDED in; in the chunk after that -- where it
+// has slid into the window's lower half, entries 0..15 -- it is used with the next table, one kTableBytes further: a constant
+// that goes into the read's offset field, since an entry's index is static in the unrolled chunk.
+template <bool Resident>
+__device__ __forceinline__ constexpr int slid_offset(int entry_index) { return Resident && entry_index < 16 ? kTableBytes : 0; }
 
 // A wave-uniform 32-bit value the optimiser cannot see through, kept in an SGPR.  Two uses: (a) 64-bit comparisons of
 // uniform values are done on the VALU (there is no s_cmp_lt_i64) unless they are taken apart into 32-bit halves that the
@@ -694,7 +704,7 @@ __device__ __forceinline__ void find_marked(uint32_t l, const uint32_t (&cur)[kR
 // its middle already), restart crossed cells from score 0 on the way, and write the exact result over `nxt`.
 // At step t the low cell of register r of lane l is (row t, column c) and the high cell (row t - 1, column c),
 // c = wave_diag0 + 32 l + 2 r + t.
-template <int Q, int NSTEPS, int... I>
+template <bool Resident, int Q, int NSTEPS, int... I>
 __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
                                             unsigned long long lanes, int report_from, const HitSink& sink, uint32_t& staged,
                                             uint32_t step0, int64_t wave_diag0, std::integer_sequence<int, I...>) {
@@ -712,6 +722,10 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
             find_marked<Q, 0, kRegs>(l, cur, nxt, C, r, s, now, entry0, entry1);
             // the match words again, from the lane's table entries (uniform addresses: every lane reads the same)
             uint32_t w[kWindowSteps] = {0, 0, 0, 0};
+            if constexpr (Resident) {      // (the register's number is only known here: the slid entries' constant, see slid_offset)
+                entry0 += 2 * Q + r < 16 ? (uint32_t)kTableBytes : 0u;
+                entry1 += 2 * Q + 1 + r < 16 ? (uint32_t)kTableBytes : 0u;
+            }
             const u32x2 wa = match_words<2 * Q>(entry0);
             w[0] = (uint32_t)__builtin_amdgcn_readfirstlane(wa.x);
             w[1] = (uint32_t)__builtin_amdgcn_readfirstlane(wa.y);
@@ -769,7 +783,7 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
 // Steps 4Q .. 4Q+3 of the chunk.  `cur` is left untouched (the first add is not in place) and holds the scores the window
 // started from; `nxt` receives the scores after the four steps; the next window swaps the two sets.  One hit test at
 // the end where the chunk flags (ssv_prepare_model) say that is exact (`safe`, wave-uniform), else one more in the middle.
-template <bool Trace, int Q, int... I>
+template <bool Trace, bool Resident, int Q, int... I>
 __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
                                             uint32_t safe, const HitSink& sink, uint32_t& staged, uint32_t step0,
                                             int64_t wave_diag0, uint32_t table_base, std::integer_sequence<int, I...> regs) {
@@ -784,7 +798,7 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
         u32x2 m[H];
         __builtin_amdgcn_sched_barrier(0);      // reads stay behind the adds before them: hoisted, they cost registers the kernel does not have
 #pragma unroll
-        for (int i = 0; i < H; i++) m[i] = match_words<2 * Q>(C[2 * Q + h * H + i]);
+        for (int i = 0; i < H; i++) m[i] = match_words<2 * Q>(C[2 * Q + h * H + i], slid_offset<Resident>(2 * Q + h * H + i));
         __builtin_amdgcn_sched_barrier(0);      // all eight reads in flight before the first add waits (hipcc otherwise staggers them)
 #pragma unroll
         for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(nxt[h * H + i]) : "v"(cur[h * H + i]), "v"(m[i].x));
@@ -811,7 +825,7 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
 #pragma unroll
         for (int i = 0; i < kRegs; i++) any |= nxt[i];
         if (const unsigned long long lanes = __ballot((any & kCrossedBits) != 0); __builtin_expect(lanes != 0, 0))
-            window_slow<Q, 2>(cur, nxt, C, lanes, 0, sink, staged, step0, wave_diag0, regs);
+            window_slow<Resident, Q, 2>(cur, nxt, C, lanes, 0, sink, staged, step0, wave_diag0, regs);
     }
     // steps 4Q+2, 4Q+3
 #pragma unroll
@@ -819,7 +833,7 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
         u32x2 m[H];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < H; i++) m[i] = match_words<2 * Q + 1>(C[2 * Q + 1 + h * H + i]);
+        for (int i = 0; i < H; i++) m[i] = match_words<2 * Q + 1>(C[2 * Q + 1 + h * H + i], slid_offset<Resident>(2 * Q + 1 + h * H + i));
         __builtin_amdgcn_sched_barrier(0);
         uint32_t mid[H];
         if constexpr (Trace) {
@@ -847,12 +861,12 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
 #pragma unroll
     for (int i = 0; i < kRegs; i++) any |= nxt[i];
     if (const unsigned long long lanes = __ballot((any & kCrossedBits) != 0); __builtin_expect(lanes != 0, 0))
-        window_slow<Q, kWindowSteps>(cur, nxt, C, lanes, (int)(2u - 2u * safe), sink, staged, step0, wave_diag0, regs);
+        window_slow<Resident, Q, kWindowSteps>(cur, nxt, C, lanes, (int)(2u - 2u * safe), sink, staged, step0, wave_diag0, regs);
 }
 
 // ONE step with the tables of step pair 0 (the step behind the model's last chunk: the high cells run one row behind
 // and still owe the last row; the low cells add a padding row, which scores 0).
-template <bool Trace, int... I>
+template <bool Trace, bool Resident, int... I>
 __device__ __forceinline__ void step_last(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
                                           const HitSink& sink, uint32_t& staged, uint32_t step0, int64_t wave_diag0,
                                           uint32_t table_base, std::integer_sequence<int, I...> regs) {
@@ -864,7 +878,7 @@ __device__ __forceinline__ void step_last(const uint32_t (&cur)[kRegs], uint32_t
         u32x2 m[H];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < H; i++) m[i] = match_words<0>(C[h * H + i]);
+        for (int i = 0; i < H; i++) m[i] = match_words<0>(C[h * H + i], slid_offset<Resident>(h * H + i));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(nxt[h * H + i]) : "v"(cur[h * H + i]), "v"(m[i].x));
@@ -878,19 +892,62 @@ __device__ __forceinline__ void step_last(const uint32_t (&cur)[kRegs], uint32_t
 #pragma unroll
     for (int i = 0; i < kRegs; i++) any |= nxt[i];
     if (const unsigned long long lanes = __ballot((any & kCrossedBits) != 0); __builtin_expect(lanes != 0, 0))
-        window_slow<0, 1>(cur, nxt, C, lanes, 0, sink, staged, step0, wave_diag0, regs);
+        window_slow<Resident, 0, 1>(cur, nxt, C, lanes, 0, sink, staged, step0, wave_diag0, regs);
 }
 
 // windows 0 .. N-1 of a chunk; the scores are in `a` on entry and, N being even, in `a` again on exit
-template <bool Trace, int... Q>
+template <bool Trace, bool Resident, int... Q>
 __device__ __forceinline__ void step_windows(uint32_t (&a)[kRegs], uint32_t (&b)[kRegs], uint32_t (&C)[32],
                                              const LazySymbols& z, uint32_t safe, const HitSink& sink, uint32_t& staged,
                                              uint32_t step0, int64_t wave_diag0, std::integer_sequence<int, Q...>) {
     static_assert(sizeof...(Q) % 2 == 0 && sizeof...(Q) * kWindowSteps == kChunkRows, "a whole chunk, an even number of windows");
     ((expand_for_window<Q>(C, z),
-      (Q % 2 == 0 ? step_window<Trace, Q>(a, b, C, safe, sink, staged, step0, wave_diag0, z.table_base, std::make_integer_sequence<int, kRegs>{})
-                  : step_window<Trace, Q>(b, a, C, safe, sink, staged, step0, wave_diag0, z.table_base, std::make_integer_sequence<int, kRegs>{}))), ...);
+      (Q % 2 == 0 ? step_window<Trace, Resident, Q>(a, b, C, safe, sink, staged, step0, wave_diag0, z.table_base, std::make_integer_sequence<int, kRegs>{})
+                  : step_window<Trace, Resident, Q>(b, a, C, safe, sink, staged, step0, wave_diag0, z.table_base, std::make_integer_sequence<int, kRegs>{}))), ...);
     expand_entry<15>(C, z);      // entry 31: entry 15 of the next chunk
+}
+
+// ---- block tails ----------------------------------------------------------------------------------------------------
+// (the end of every SSV kernel body: `stage` = the wave's staged records, `staged` of them, wave-uniform)
+__device__ __forceinline__ void leave_block(const uint64_t* const stage, const uint32_t staged, const uint32_t wave) {
+    // What is still staged when the block ends.  A returning atomic on the one counter word is the obvious way out, and
+    // for short models the wrong one: the word sustains ~90 returning atomics per microsecond chip-wide, a launch of
+    // one-chunk tiles ends 100+ blocks per microsecond, and every one of them waits ~2 us for its answer.  So the block
+    // writes its tail -- up to kTailSlots records -- with plain stores into ITS OWN slots of a side buffer, notes the count
+    // and is gone; ssv_gather_tails, a small kernel behind this one, moves the tails into the queue with one atomic per
+    // 256 blocks.  A tail that does not fit (or a launch too big for a side buffer) takes the atomic, once per block.
+    __shared__ uint32_t block_staged[kWavesPerBlock];
+    __shared__ unsigned long long block_base;
+    const uint32_t lane_again = __lane_id();     // not kept through the items: two instructions here
+    if (lane_again == 0) block_staged[wave] = staged;
+    __syncthreads();
+    uint32_t total = 0, before_me = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; w++) { total += block_staged[w]; before_me += (uint32_t)w < wave ? block_staged[w] : 0u; }
+    const rare_args_t rare = rare_args();
+    uint64_t* const tails = rare->tails;
+    if (tails && total <= (uint32_t)kTailSlots) {
+        if (wave == 0 && lane_again == 0) rare->tail_counts[blockIdx.x] = total;
+        if (staged) {
+            const uint32_t row_bits = rare->row_bits;
+            uint64_t* const mine = tails + (size_t)blockIdx.x * kTailSlots + before_me;
+            for (uint32_t i = lane_again; i < staged; i += 64) mine[i] = staged_to_key(stage[i], row_bits);
+        }
+        return;
+    }
+    if (wave == 0 && lane_again == 0) {      // (not threadIdx.x: it would sit in a VGPR -- in scratch -- from the kernel's first instruction on)
+        if (tails) rare->tail_counts[blockIdx.x] = 0;
+        block_base = total ? atomicAdd(rare->hit_count, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    if (staged) {
+        uint64_t* const hits = rare->hits;
+        const uint64_t capacity = rare->hit_capacity;
+        const uint32_t row_bits = rare->row_bits;
+        const unsigned long long base = block_base + before_me;
+        for (uint32_t i = lane_again; i < staged; i += 64)
+            if (base + i < capacity) hits[base + i] = staged_to_key(stage[i], row_bits);
+    }
 }
 
 // selector of the match word of symbol a: bytes [0x0c, a, 0x0c, 4 + a]; with v_perm(S0 = row t-1, S1 = row t) it
@@ -915,24 +972,7 @@ constexpr uint32_t kHandoffSpins = 1u << 26;   // x ~1 us: a minute, far beyond 
 // few temporaries.  Nothing else is kept in a VGPR through the windows: no lane number (LaneWords, fresh_lane), no
 // SGPR spills (SsvRare).  The sixth wave is worth 3 % (C2 kernel 1.93 -> 1.87 ms); a seventh (72 VGPRs) needs batches of
 // four match-word pairs and spills in the chunk epilogue.
-// ---- the short-model variant (Short) ---------------------------------------------------------------------------------------
-// A tile of a short model -- one to four 32-row chunks -- is mostly prologue: of the ~22,500 cycles a one-chunk tile's wave
-// lives, the chunk takes 11,900; the rest is latency in a row (kernarg loads of the item's decode, the first symbols, then
-// window + second symbols + model rows: two trips to memory one after the other) and ~2 us of empty wave slot between a
-// workgroup's end and its successor's start.  The reference's array has no such dependence on the
-// model's height (README.md:4; device/HavacHls.cpp:220-319: one row per clock whatever L is).  The second instantiation of
-// the SAME body for launches whose items are at most kShortItemRows rows:
-//   * five waves per SIMD (96 VGPRs): room for eight registers that carry loads across a whole tile;
-//   * a wave WALKS a group of adjacent tiles (SsvRare::tiles_per_item), and the first loads of tile g+1 -- its first two
-//     symbol words, its first model rows, the abort word -- are ISSUED AT THE START OF TILE g and consumed a tile later: no
-//     tile of a walk but the first waits for memory in its prologue, so the waves of a round can walk in step without
-//     stalling in step (what made walking a loss in round 3), a workgroup's start and end are paid once per group, and the
-//     item is decoded once per walk;
-//   * no separator mask, no row blocks, no trace: the host (havac_dev.hip, pick_kernel) takes the standard kernel for those.
-constexpr uint32_t kShortItemRows = 128;
-struct TileLoads { uint2 w0, w1; uint32_t r0, r1, r2, abort_word; };      // Short: what a tile's prologue needs from memory
-
-template <bool Trace, bool Short = false>
+template <bool Trace>
 __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
                                               const uint32_t* __restrict__ safe_chunks, const int64_t nsymbols,
                                               const uint32_t nrows_padded) {
@@ -941,12 +981,11 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
     const uint32_t lane = threadIdx.x & 63;
     // a separator mask is in use exactly when there are no chunk flags; as a 32-bit SGPR flag tested afresh (fresh_uniform), not a
     // lane mask that is copied through -- and once spilled from -- a VGPR
-    // (Short: never launched with a separator mask -- a constant, and every branch on it is gone)
-    const uint32_t has_mask = Short ? 0u : opaque_uniform(safe_chunks == nullptr ? 1u : 0u);
+    const uint32_t has_mask = opaque_uniform(safe_chunks == nullptr ? 1u : 0u);
     // readfirstlane: everything derived from the tile index is wave-uniform (SALU branches, scalar address math)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds* const lds = &wave_lds[wave];
-    const HitSink sink{lds};
+    const HitSink sink{lds->stage};
     uint32_t staged = 0;          // wave-uniform
 
     // LDS byte address of this wave's tables (a multiple of 128: code*8 is OR-ed into it)
@@ -969,15 +1008,11 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
     }
 
     // ---- one item: tile `tile_in_launch` of the launch, all of its rows or (cut != 0) its row block `block` ---------------
-    TileLoads ahead{};                 // Short: the first loads of the walk's NEXT tile, in flight across the current one
     auto run_item = [&](const uint32_t tile_arg, const uint32_t block_arg /* kWholeTile: all rows */,
-                        const uint32_t slot_arg /* cut tiles: the tile's hand-off slot */,
-                        const uint32_t fetch_ahead /* Short: 0 = this tile's first loads are issued here (the walk's first tile), 1 = they
-                                                      are in `ahead`; bit 1: issue the next tile's */) -> bool {   // false: stop (abort requested, or a hand-off never came)
+                        const uint32_t slot_arg /* cut tiles: the tile's hand-off slot */) -> bool {   // false: stop (abort requested, or a hand-off never came)
         // (wave-uniform, but a division may have left them in vector registers)
-        const uint32_t tile_in_launch = __builtin_amdgcn_readfirstlane(tile_arg);
-        const uint32_t block = Short ? kWholeTile : __builtin_amdgcn_readfirstlane(block_arg);
-        const uint32_t handoff_slot = Short ? 0u : __builtin_amdgcn_readfirstlane(slot_arg);
+        const uint32_t tile_in_launch = __builtin_amdgcn_readfirstlane(tile_arg), block = __builtin_amdgcn_readfirstlane(block_arg);
+        const uint32_t handoff_slot = __builtin_amdgcn_readfirstlane(slot_arg);
         const uint32_t cut = block != kWholeTile ? 1u : 0u;
         const rare_args_t launch = rare_args();
         const uint32_t tile = launch->tile_begin + tile_in_launch;
@@ -1000,17 +1035,16 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             if (p_begin < b0) p_begin = b0;
             if (p_end > b1) p_end = b1;
         }
-        if constexpr (!Short) { if (p_begin >= p_end) return true; }      // (Short: behind the loads of the walk's next tile, below)
+        if (p_begin >= p_end) return true;
         // An abort request stops every item that has not started yet: a run of short models, whose items never reach the
         // 2048-row poll below, drains at once too.  The word is read past the caches -- a trip to memory -- so the load is
         // ISSUED here and looked at behind the item's first loads (symbols, model rows), with which it travels: tested at
         // once, it cost a one-chunk tile a memory latency of its own before anything else had started.
         uint32_t abort_now = 0;
-        auto load_abort_word = [&]() -> uint32_t {
+        {
             const uint32_t* const abort_flag = rare_args()->abort_flag;
-            return abort_flag ? __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
-        };
-        if constexpr (!Short) abort_now = load_abort_word();
+            if (abort_flag) abort_now = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
 
         uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_window)
         // (uniform base, lane offset added where it is used: a per-lane 64-bit pointer would sit in two VGPRs through the item)
@@ -1112,49 +1146,11 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         };
         LazySymbols z;
         LaneWords mine = read_lane_words(lane_words_address);
-        ModelRows next_rows;
-        if constexpr (Short) {
-            // A tile's first loads, all in flight before anything waits: the symbols of its first two chunks, its first model
-            // rows, the abort word.  (whole tiles only: rows from the tile's own p_lo; the ranges are recomputed where the words
-            // are consumed -- scalar arithmetic -- so that only the loaded words travel)
-            auto issue_tile_loads = [&](const uint32_t t_in_launch, TileLoads& L) {
-                const rare_args_t launch2 = rare_args();
-                const int64_t t_d0 = launch2->first_diag + (int64_t)(launch2->tile_begin + t_in_launch) * kTileDiags;
-                int64_t t_lo = -t_d0 - kTileDiags;
-                if (t_lo < 0) t_lo = 0;
-                if (t_lo > (int64_t)nrows_padded) t_lo = nrows_padded;
-                const uint32_t t_begin = __builtin_amdgcn_readfirstlane((uint32_t)t_lo);
-                auto range_of = [&](int64_t rel) -> SymbolRange {
-                    SymbolRange e;
-                    e.first = t_d0 + rel;
-                    e.valid_lo = clamp_to_4096(-e.first);
-                    e.valid_hi = clamp_to_4096(nsymbols - e.first);
-                    e.edge = (uint32_t)(e.valid_lo != 0) | (uint32_t)(e.valid_hi < kTileDiags);
-                    return e;
-                };
-                uint32_t no_separators;
-                load_symbols(range_of(t_begin), mine.lane8, L.w0, no_separators);
-                const ModelRows r = fetch_rows(t_begin, mine);
-                L.r0 = r.r0; L.r1 = r.r1; L.r2 = r.r2;
-                load_symbols(range_of(t_begin + 32), mine.lane8, L.w1, no_separators);
-                L.abort_word = load_abort_word();
-            };
-            if (!(fetch_ahead & 1u)) issue_tile_loads(tile_in_launch, ahead);       // the walk's first tile: nothing was issued for it yet
-            const TileLoads now = ahead;
-            if (fetch_ahead & 2u) issue_tile_loads(tile_in_launch + 1u, ahead);     // the next tile's, a whole tile ahead of their use
-            if (p_begin >= p_end) return true;                                      // (a tile without rows: never expected inside a launch's range)
-            finish_symbols(symbol_range(p_begin), now.w0, 0u, z);
-            if (__builtin_amdgcn_readfirstlane(now.abort_word)) return false;
-            expand_all(C, z, std::make_integer_sequence<int, 16>{});
-            next_rows = ModelRows{now.r0, now.r1, now.r2, mine.sel_second, mine.entries};
-            finish_symbols(symbol_range(p_begin + 32), now.w1, 0u, z);
-        } else {
-            fetch_symbols(p_begin, z, mine.lane8);
-            if (__builtin_amdgcn_readfirstlane(abort_now)) return false;       // (a scalar branch: every lane read the same word)
-            expand_all(C, z, std::make_integer_sequence<int, 16>{});       // -> C[16..32): the first chunk's lower half after the slide
-            next_rows = fetch_rows(p_begin, mine);
-            fetch_symbols(p_begin + 32, z, mine.lane8);
-        }
+        fetch_symbols(p_begin, z, mine.lane8);
+        if (__builtin_amdgcn_readfirstlane(abort_now)) return false;       // (a scalar branch: every lane read the same word)
+        expand_all(C, z, std::make_integer_sequence<int, 16>{});       // -> C[16..32): the first chunk's lower half after the slide
+        ModelRows next_rows = fetch_rows(p_begin, mine);
+        fetch_symbols(p_begin + 32, z, mine.lane8);
         // The global loads of a chunk (12 B of model rows and 8 B of symbols per lane) are issued at the END of the chunk
         // before it and consumed at its top: no register carries them across the windows, and the latency that is
         // exposed this way is covered by the other four waves of the SIMD (measured in round 1: 2.12 ms against 2.16 ms
@@ -1163,27 +1159,24 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         bool go_on = true;                 // wave-uniform
         // one bit per chunk: may the chunk look for hits every four steps only (ssv_prepare_model)?  never with separators.
         // The word of the current 1024 rows and, loaded a whole block ahead, the next one: the test never waits for memory
-        // (Short: a model of at most kShortItemRows rows lies inside the first flag word, and no item is long enough for a poll)
-        uint32_t safe_now = Short ? safe_chunks[0] : (safe_chunks ? safe_chunks[p_begin >> 10] : 0u);
-        uint32_t safe_next = Short ? 0u : (safe_chunks ? safe_chunks[(p_begin >> 10) + 1] : 0u);
+        uint32_t safe_now = safe_chunks ? safe_chunks[p_begin >> 10] : 0u;
+        uint32_t safe_next = safe_chunks ? safe_chunks[(p_begin >> 10) + 1] : 0u;
         for (uint32_t p0 = p_begin; p0 < p_end; p0 += kChunkRows) {
-            if constexpr (!Short) {
-                if ((p0 & 1023) == 0 && p0 != p_begin) {
-                    safe_now = safe_next;
-                    safe_next = safe_chunks ? safe_chunks[(p0 >> 10) + 1] : 0u;
-                }
-                // abort: a device word, read past the caches every 2048 rows inside an item (and between items, below)
-                if (((p0 & 2047) == 0) && p0 != p_begin) {
-                    const uint32_t* const abort_flag = rare_args()->abort_flag;
-                    if (abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { go_on = false; break; }
-                }
+            if ((p0 & 1023) == 0 && p0 != p_begin) {
+                safe_now = safe_next;
+                safe_next = safe_chunks ? safe_chunks[(p0 >> 10) + 1] : 0u;
+            }
+            // abort: a device word, read past the caches every 2048 rows inside an item (and between items, below)
+            if (((p0 & 2047) == 0) && p0 != p_begin) {
+                const uint32_t* const abort_flag = rare_args()->abort_flag;
+                if (abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { go_on = false; break; }
             }
             build_tables(next_rows);
             // slide the window by 32 symbols
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
             const uint32_t safe = opaque_uniform((safe_now >> ((p0 >> 5) & 31u)) & 1u);
-            step_windows<Trace>(x, x2, C, z, safe, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
+            step_windows<Trace, false>(x, x2, C, z, safe, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
             asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the windows
             mine = read_lane_words(lane_words_address);
             next_rows = fetch_rows(p0 + kChunkRows, mine);        // rows[] has kModelSlack words behind the model
@@ -1195,7 +1188,7 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             build_tables(next_rows);                               // fetched for p_end by the last chunk
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-            step_last<Trace>(x, x2, C, sink, staged, p_end, d0, table_base, std::make_integer_sequence<int, kRegs>{});
+            step_last<Trace, false>(x, x2, C, sink, staged, p_end, d0, table_base, std::make_integer_sequence<int, kRegs>{});
         } else if (p_end < p_hi) {
             // the tile goes on in the next row block: hand the scores over (release: the stores, then the count)
             const rare_args_t rare = rare_args();
@@ -1239,82 +1232,253 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         // row-block-major.  (Decoded afresh for every tile of a walk -- a dozen scalar instructions: only `item` and the count
         // stay alive across a tile, and the hot loop is as short of scalar registers as of vector ones.  ONE call site of run_item:
         // with two, hipcc stops inlining it -- and a called function cannot read the kernarg segment.)
-        // (Short: decoded once per walk, and only the walk -- first tile, length -- lives across its tiles)
-        uint32_t first_tile = 0, walk = 0, block = kWholeTile, slot = 0;
         for (uint32_t g = 0;; g++) {
-            if (!Short || g == 0) {
-                const rare_args_t plan = rare_args();
-                const uint32_t t0 = plan->part_begin[part], t1 = plan->part_begin[part + 1u];
-                const uint32_t mine = t1 - t0, cut_limit = plan->split_units;
-                const uint32_t cut_units = cut_limit < mine ? cut_limit : mine, whole = mine - cut_units;
-                const uint32_t per_group = plan->tiles_per_item, single_tiles = plan->single_tiles;
-                const uint32_t groups = per_group > 1 ? (whole - (single_tiles < whole ? single_tiles : whole)) / per_group : 0u;
-                const uint32_t singles = whole - groups * per_group;
-                // A cut tile's hand-off slot (SsvRare::block_flags / block_state): cut tile u of partition k has slot k * split_units + u
-                // -- the buffers hold the launch's CUT tiles only (C4's rank: 9,216 of 61,000 tiles; a 3 Gbp genome against a tall
-                // model: 18 MB instead of 3 GB) -- or, where every tile is cut (split_units = all ones), the tile's own number.
-                first_tile = 0; walk = 0; block = kWholeTile; slot = 0;
-                if (item < groups) {
-                    first_tile = t0 + item * per_group;
-                    walk = per_group;
-                } else if (item - groups < singles) {
-                    first_tile = t0 + groups * per_group + (item - groups);
-                    walk = 1;
-                } else if (item - groups - singles < cut_units * plan->nrow_blocks) {
-                    const uint32_t j = item - groups - singles;
-                    block = j / cut_units;
-                    const uint32_t unit = j - block * cut_units;
-                    first_tile = t0 + whole + unit;
-                    slot = cut_limit == 0xffffffffu ? first_tile : part * cut_limit + unit;
-                    walk = 1;
-                }
+            const rare_args_t plan = rare_args();
+            const uint32_t t0 = plan->part_begin[part], t1 = plan->part_begin[part + 1u];
+            const uint32_t mine = t1 - t0, cut_limit = plan->split_units;
+            const uint32_t cut_units = cut_limit < mine ? cut_limit : mine, whole = mine - cut_units;
+            const uint32_t per_group = plan->tiles_per_item, single_tiles = plan->single_tiles;
+            const uint32_t groups = per_group > 1 ? (whole - (single_tiles < whole ? single_tiles : whole)) / per_group : 0u;
+            const uint32_t singles = whole - groups * per_group;
+            // A cut tile's hand-off slot (SsvRare::block_flags / block_state): cut tile u of partition k has slot k * split_units + u
+            // -- the buffers hold the launch's CUT tiles only (C4's rank: 9,216 of 61,000 tiles; a 3 Gbp genome against a tall
+            // model: 18 MB instead of 3 GB) -- or, where every tile is cut (split_units = all ones), the tile's own number.
+            uint32_t first_tile = 0, walk = 0, block = kWholeTile, slot = 0;
+            if (item < groups) {
+                first_tile = t0 + item * per_group;
+                walk = per_group;
+            } else if (item - groups < singles) {
+                first_tile = t0 + groups * per_group + (item - groups);
+                walk = 1;
+            } else if (item - groups - singles < cut_units * plan->nrow_blocks) {
+                const uint32_t j = item - groups - singles;
+                block = j / cut_units;
+                const uint32_t unit = j - block * cut_units;
+                first_tile = t0 + whole + unit;
+                slot = cut_limit == 0xffffffffu ? first_tile : part * cut_limit + unit;
+                walk = 1;
             }
-            // Short: a tile's first loads are issued a tile ahead (bit 0: this tile's are in flight already; bit 1: issue the next one's)
-            const uint32_t fetch_ahead = Short ? ((g != 0 ? 1u : 0u) | (g + 1u < walk ? 2u : 0u)) : 0u;
-            // (no row blocks in a Short launch: every item is a run of whole tiles, and nothing of the hand-off is compiled in)
-            if (g >= walk || !run_item(first_tile + g, Short ? kWholeTile : block, Short ? 0u : slot, fetch_ahead)) break;
+            if (g >= walk || !run_item(first_tile + g, block, slot)) break;
         }
     }
 
-    // ---- block tails ----------------------------------------------------------------------------------------------------
-    // What is still staged when the block ends.  A returning atomic on the one counter word is the obvious way out, and
-    // for short models the wrong one: the word sustains ~90 returning atomics per microsecond chip-wide, a launch of
-    // one-chunk tiles ends 100+ blocks per microsecond, and every one of them waits ~2 us for its answer.  So the block
-    // writes its tail -- up to kTailSlots records -- with plain stores into ITS OWN slots of a side buffer, notes the count
-    // and is gone; ssv_gather_tails, a small kernel behind this one, moves the tails into the queue with one atomic per
-    // 256 blocks.  A tail that does not fit (or a launch too big for a side buffer) takes the atomic, once per block.
-    __shared__ uint32_t block_staged[kWavesPerBlock];
-    __shared__ unsigned long long block_base;
-    const uint32_t lane_again = __lane_id();     // not kept through the items: two instructions here
-    if (lane_again == 0) block_staged[wave] = staged;
-    __syncthreads();
-    uint32_t total = 0, before_me = 0;
+    leave_block(lds->stage, staged, wave);
+}
+
+// ---- the resident-table variant (short models) ---------------------------------------------------------------------------
+// A tile of a short model -- one to eight 32-row chunks -- is mostly prologue in the kernel above: of the ~22,500 cycles a
+// one-chunk tile's wave lives, the chunk takes 11,900; the rest is latency in a row (a workgroup's start, the item's decode,
+// the first symbols, then window + second symbols + model rows, the rows of the step behind the chunk) and ~2 us of empty
+// wave slot between a workgroup's end and its successor's start.  The reference's array has no such
+// dependence on the model's height (README.md:4; device/HavacHls.cpp:220-319: one row per clock whatever L is).  What a
+// short model makes possible:
+//   * ALL its tables fit LDS at once -- (chunks + 1) x 2.25 KB, the same for every tile of the launch -- so a workgroup builds
+//     them ONCE (its four waves share them) instead of once per chunk and wave: no model rows loaded, no v_perm, no table
+//     write, no wait for either inside a tile.  A window entry is `table | code*8`; the entries that slide from one chunk's
+//     window into the next use the next table through the read's offset field (slid_offset), so nothing is re-based;
+//   * the launch is as many workgroups as the chip holds at once, and every wave WALKS its own run of adjacent tiles (equal
+//     runs, handed out by the wave's number alone): a workgroup's start, end and empty slot are paid once per launch, not
+//     once per four tiles, and nothing but the wave's own stage flush ever touches the hit counter;
+//   * the next tile's first symbols are fetched before the step behind the current tile's last chunk.
+// No separator mask, no row blocks, no trace: the host (havac_dev.hip, pick_resident_kernel) takes the standard kernel there.
+#ifdef HAVAC_WAVE_CLOCKS
+// experiments only (tools/wave_clocks.py): when each wave of the resident-table kernel started its run and left it, on the
+// chip-wide 100 MHz clock, and which SIMD it ran on
+__device__ uint64_t g_wave_clocks[4 * 16384];
+#endif
+constexpr uint32_t kResidentRows = 256;                             // models of up to this many (padded) rows
+constexpr int kResidentTables = kResidentRows / kChunkRows + 1;     // + the table of the step behind the last chunk
+struct __attribute__((aligned(128))) ResidentLds {
+    uint64_t stage[kWavesPerBlock][kHitStage];      // in front of the tables: "one table below table 0" (the base the first
+    uint8_t table[kResidentTables][kTableBytes];    //   chunk's slid entries carry) must still be an LDS address
+};
+static_assert(sizeof(uint64_t) * kWavesPerBlock * kHitStage >= kTableBytes, "the stages cover one table's worth of addresses");
+
+struct TileSymbols { uint2 w0, w1; uint32_t abort_word; };      // what a tile's prologue needs from memory
+
+__device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
+                                                  const uint32_t* __restrict__ safe_chunks, const int64_t nsymbols,
+                                                  const uint32_t nrows_padded) {
+    __shared__ ResidentLds lds;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const HitSink sink{lds.stage[wave]};
+    uint32_t staged = 0;          // wave-uniform
+    const uint32_t tables = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds.table);
+    const uint32_t nchunks = nrows_padded / kChunkRows;
+
+    // ---- the tables, once per workgroup: table c = chunk c's 16 step-pair tables (see build_tables in ssv_diag_body), table
+    // nchunks = the step behind the last chunk (its pair 0: the model's last row for the high cells, a padding row for the low)
+    {
+        const uint32_t lane = fresh_lane();
+        const uint32_t my_pair = lane >> 2, my_b = lane & 3;
+        for (uint32_t c = wave; c <= nchunks; c += kWavesPerBlock) {
+            const uint32_t* const r = rows + c * kChunkRows + my_pair * 2;       // rows[] is shifted by one: rows[t] is M[t-1]
+            const uint32_t r0 = r[0], r1 = r[1], r2 = r[2];
+            const uint32_t second = __builtin_amdgcn_perm(r1, r2, word_selector(my_b));
+            const uint32_t at = tables + c * kTableBytes + my_pair * kPairStride;
+            const lds_words_out_t out = (lds_words_out_t)(uintptr_t)(at + my_b * 32);
 #pragma unroll
-    for (int w = 0; w < kWavesPerBlock; w++) { total += block_staged[w]; before_me += (uint32_t)w < wave ? block_staged[w] : 0u; }
-    const rare_args_t rare = rare_args();
-    uint64_t* const tails = rare->tails;
-    if (tails && total <= (uint32_t)kTailSlots) {
-        if (wave == 0 && lane_again == 0) rare->tail_counts[blockIdx.x] = total;
-        if (staged) {
-            const uint32_t row_bits = rare->row_bits;
-            uint64_t* const mine = tails + (size_t)blockIdx.x * kTailSlots + before_me;
-            for (uint32_t i = lane_again; i < staged; i += 64) mine[i] = staged_to_key(lds->stage[i], row_bits);
+            for (int a = 0; a < 4; a++) out[a] = u32x2{__builtin_amdgcn_perm(r0, r1, word_selector(a)), second};
+            if (my_b == 0) *(lds_words_out_t)(uintptr_t)(at + kOutsideCode) = u32x2{kOutsideNeutral, kOutsideNeutral};
         }
-        return;
-    }
-    if (wave == 0 && lane_again == 0) {      // (not threadIdx.x: it would sit in a VGPR -- in scratch -- from the kernel's first instruction on)
-        if (tails) rare->tail_counts[blockIdx.x] = 0;
-        block_base = total ? atomicAdd(rare->hit_count, (unsigned long long)total) : 0ull;
     }
     __syncthreads();
-    if (staged) {
-        uint64_t* const hits = rare->hits;
-        const uint64_t capacity = rare->hit_capacity;
-        const uint32_t row_bits = rare->row_bits;
-        const unsigned long long base = block_base + before_me;
-        for (uint32_t i = lane_again; i < staged; i += 64)
-            if (base + i < capacity) hits[base + i] = staged_to_key(lds->stage[i], row_bits);
+
+    // ---- this wave's run of tiles
+    uint32_t tile, tile_end;
+    {
+        const rare_args_t plan = rare_args();
+        const uint32_t g = blockIdx.x * kWavesPerBlock + wave, slots = plan->walk_slots, last = plan->walk_rounds - 1u;
+        uint32_t round = g / slots;
+        if (round > last) round = last;
+        const uint32_t len = plan->walk_len[round];
+        tile = plan->walk_base[round] + (g - round * slots) * len;
+        tile_end = tile + len;
+        const uint32_t ntiles = plan->ntiles;
+        if (tile > ntiles) tile = ntiles;
+        if (tile_end > ntiles) tile_end = ntiles;
     }
+    const uint32_t safe_word = safe_chunks[0];        // a model of up to 1024 rows lies inside the first flag word
+
+    struct SymbolRange { int64_t first; int32_t valid_lo, valid_hi; uint32_t edge; };
+    auto symbol_range = [&](int64_t first) -> SymbolRange {          // the wave's 2048 positions from `first` on (see ssv_diag_body)
+        SymbolRange e;
+        e.first = first;
+        e.valid_lo = clamp_to_4096(-first);
+        e.valid_hi = clamp_to_4096(nsymbols - first);
+        e.edge = (uint32_t)(e.valid_lo != 0) | (uint32_t)(e.valid_hi < kTileDiags);
+        return e;
+    };
+    auto load_symbols = [&](const SymbolRange& e, const uint32_t lane8) -> uint2 {
+        const uint8_t* const base = seq + (e.first >> 2);             // only dereferenced for lanes inside [0, N)
+        uint2 w = make_uint2(0u, 0u);
+        if (!e.edge) w = *reinterpret_cast<const uint2*>(base + lane8);
+        else if ((int32_t)(lane8 * 4) >= e.valid_lo && (int32_t)(lane8 * 4) + 32 <= e.valid_hi) w = *reinterpret_cast<const uint2*>(base + lane8);
+        return w;
+    };
+    auto finish_symbols = [&](const SymbolRange& e, const uint2 w, const uint32_t table_base, LazySymbols& z) {
+        z.valid_lo = e.valid_lo; z.valid_hi = e.valid_hi;
+        z.table_base = table_base;
+        z.separators = 0;
+        z.special = opaque_uniform(e.edge);
+        prepare_symbols(z, w.x, w.y);
+    };
+    // a tile's first diagonal and the first of its rows that can lie inside the matrix (ssv_diag_body: d0, p_lo)
+    auto tile_start = [&](const uint32_t t, int64_t& d0, uint32_t& p_lo) {
+        const rare_args_t launch = rare_args();
+        d0 = launch->first_diag + (int64_t)(launch->tile_begin + t) * kTileDiags;
+        int64_t lo64 = -d0 - kTileDiags;
+        if (lo64 < 0) lo64 = 0;
+        if (lo64 > (int64_t)nrows_padded) lo64 = nrows_padded;
+        p_lo = __builtin_amdgcn_readfirstlane((uint32_t)lo64);
+    };
+    // A tile's first loads, all in flight before anything waits: the symbols of its first two chunks and the abort word (read
+    // past the caches; it travels with the symbols).  The ranges are recomputed where the words are consumed -- scalar
+    // arithmetic -- so that only the loaded words are carried.
+    auto issue_tile_loads = [&](const uint32_t t, TileSymbols& L) {
+        int64_t t_d0; uint32_t t_lo;
+        tile_start(t, t_d0, t_lo);
+        const uint32_t lane8 = fresh_lane() * 8u;
+        L.w0 = load_symbols(symbol_range(t_d0 + t_lo), lane8);
+        L.w1 = load_symbols(symbol_range(t_d0 + t_lo + 32), lane8);
+        const uint32_t* const abort_flag = rare_args()->abort_flag;
+        L.abort_word = abort_flag ? __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+    };
+
+    TileSymbols ahead{};               // the first loads of the run's NEXT tile, in flight across the end of the current one
+    auto run_tile = [&](const uint32_t tile_arg, const uint32_t more_arg /* 1: another tile follows in this wave's run */) -> bool {
+        const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_arg), more = __builtin_amdgcn_readfirstlane(more_arg);
+        int64_t d0; uint32_t p_lo;
+        tile_start(tile, d0, p_lo);
+        int64_t hi64 = rare_args()->col_end - d0;                                  // first row entirely right of the shard's columns
+        if (hi64 > (int64_t)nrows_padded) hi64 = nrows_padded;
+        if (hi64 < 0) hi64 = 0;
+        const uint32_t p_hi = __builtin_amdgcn_readfirstlane((uint32_t)hi64);
+        const TileSymbols now = ahead;
+        // (`ahead` is written on every path: kept conditionally, its OLD words would stay alive through the chunk loop)
+        ahead = TileSymbols{};
+        if (p_lo >= p_hi) {                                              // (a tile without rows: never expected inside a launch's range)
+            if (more) issue_tile_loads(tile + 1, ahead);
+            return true;
+        }
+        if (__builtin_amdgcn_readfirstlane(now.abort_word)) return false;       // abort: a device word, looked at once per tile
+        uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_window)
+#pragma unroll
+        for (int i = 0; i < kRegs; i++) x[i] = x2[i] = kScoreZero;
+        uint32_t C[32];
+        LazySymbols z;
+        const uint32_t first_table = tables + (p_lo / kChunkRows) * kTableBytes;
+        finish_symbols(symbol_range(d0 + p_lo), now.w0, first_table - kTableBytes, z);
+        expand_all(C, z, std::make_integer_sequence<int, 16>{});       // -> C[16..32): the first chunk's lower half after the slide
+        finish_symbols(symbol_range(d0 + p_lo + 32), now.w1, first_table, z);
+        for (uint32_t p0 = p_lo; p0 < p_hi; p0 += kChunkRows) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) C[k] = C[k + 16];
+            const uint32_t safe = opaque_uniform((safe_word >> (p0 >> 5)) & 1u);
+            step_windows<false, true>(x, x2, C, z, safe, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
+            asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the windows
+            if (p0 + kChunkRows < p_hi) {
+                // the next chunk's upper half (issued at the end of a chunk, consumed at the top of the next: see ssv_diag_body)
+                const SymbolRange e = symbol_range(d0 + p0 + kChunkRows + 32);
+                finish_symbols(e, load_symbols(e, fresh_lane() * 8u), tables + ((p0 >> 5) + 1u) * kTableBytes, z);
+            }
+        }
+        // the next tile's first loads: in flight across the step behind the last chunk and the next tile's scalar prologue
+        // (issued here, not inside the chunk loop: nothing of them is alive through the windows)
+        if (more) issue_tile_loads(tile + 1, ahead);
+        if (p_hi == nrows_padded) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) C[k] = C[k + 16];
+            step_last<false, true>(x, x2, C, sink, staged, p_hi, d0, 0u, std::make_integer_sequence<int, kRegs>{});
+        }
+        return true;
+    };
+#ifdef HAVAC_WAVE_CLOCKS
+    const uint64_t clock_start = __builtin_readcyclecounter() * 0 + wall_clock64();
+    const uint32_t tiles_mine = tile_end - tile;
+#endif
+    if (tile < tile_end) issue_tile_loads(tile, ahead);
+#ifdef HAVAC_RESIDENT_STAGGER
+    {   // experiment: the waves of a SIMD (one of each of the CU's six workgroups) and the SIMDs of a CU start out of step
+        const uint32_t slot = (blockIdx.x / 256u) % 6u, units = slot * 4u + wave;      // 0..23
+        for (uint32_t k = 0; k < units; k++) __builtin_amdgcn_s_sleep(HAVAC_RESIDENT_STAGGER);
+    }
+#endif
+#ifdef HAVAC_RESIDENT_ROTATE
+    const uint32_t first_of_run = tile;
+    uint32_t turn;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(turn));       // the wave's slot on its SIMD
+#endif
+    for (; tile < tile_end; tile++) {
+#ifdef HAVAC_RESIDENT_ROTATE
+        // The instruction arbiter serves the OLDEST wave of a SIMD first: left alone, the six waves of a SIMD run their equal
+        // runs almost one after the other (the first leaves after 40 % of the launch, the last runs alone at the end).  Every
+        // wave therefore takes turns at the four priority levels, a tile at a time, offset by its slot.
+#if HAVAC_RESIDENT_ROTATE == 2
+        // by what is left of the run: a wave that is ahead of its siblings drops a level and lets them catch up
+        turn = ((tile_end - tile) * 4u - 1u) / (tile_end - first_of_run);
+#endif
+        switch (turn++ & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#endif
+        if (!run_tile(tile, tile + 1 < tile_end ? 1u : 0u)) break;
+    }
+#ifdef HAVAC_WAVE_CLOCKS
+    {
+        const uint32_t g = blockIdx.x * kWavesPerBlock + wave;
+        uint32_t hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        if (fresh_lane() == 0 && g < 16384u) {
+            g_wave_clocks[4 * g] = clock_start; g_wave_clocks[4 * g + 1] = wall_clock64();
+            g_wave_clocks[4 * g + 2] = hw_id; g_wave_clocks[4 * g + 3] = tiles_mine;
+        }
+    }
+#endif
+    leave_block(lds.stage[wave], staged, wave);
 }
 
 // The tails of `nblocks` blocks (tail_counts[b] sort keys at tails[b * kTailSlots ...]) are appended to the queue.  A
@@ -1370,11 +1534,14 @@ void ssv_diag_kernel(const SsvRare /* read through rare_args(), never by name */
     ssv_diag_body<false>(seq, rows, safe_chunks, nsymbols, nrows_padded);
 }
 
-// the same body for launches of short items (see "the short-model variant"): five waves per SIMD, loads a tile ahead
-__global__ __launch_bounds__(64 * kWavesPerBlock, 5)
-void ssv_diag_kernel_short(const SsvRare, const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
-                           const uint32_t* __restrict__ safe_chunks, const int64_t nsymbols, const uint32_t nrows_padded) {
-    ssv_diag_body<false, true>(seq, rows, safe_chunks, nsymbols, nrows_padded);
+// short models (see "the resident-table variant"): as many workgroups as the chip holds, every wave walks its run of tiles
+#ifndef HAVAC_RESIDENT_WAVES
+#define HAVAC_RESIDENT_WAVES HAVAC_WAVES_PER_SIMD
+#endif
+__global__ __launch_bounds__(64 * kWavesPerBlock, HAVAC_RESIDENT_WAVES)
+void ssv_resident_kernel(const SsvRare, const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
+                         const uint32_t* __restrict__ safe_chunks, const int64_t nsymbols, const uint32_t nrows_padded) {
+    ssv_resident_body(seq, rows, safe_chunks, nsymbols, nrows_padded);
 }
 
 // the same body with the per-cell trace compiled in (see CellRecord): a debugging aid, never launched unless a trace window is set

@@ -74,7 +74,7 @@ class SsvContext:
 
     def set_kernel_variant(self, variant: int = -1):
         """which instantiation of the SSV kernel the next passes run (include/havac_dev.h: havac_ssv_set_kernel_variant):
-        -1 the library decides, 0 the standard kernel, 1 the short-model kernel wherever it is valid"""
+        -1 the library decides, 0 the standard kernel, 1 the resident-table kernel (short models) wherever it is valid"""
         self._check(self._L.havac_ssv_set_kernel_variant(self._h, variant))
 
     def last_kernel_variant(self) -> int:
@@ -158,19 +158,23 @@ class _LaunchPlan(C.Structure):
                 ("nparts", C.c_uint32), ("part_begin", C.c_uint32 * 9),
                 ("tiles_per_group", C.c_uint32), ("single_tiles", C.c_uint32), ("cut_tiles", C.c_uint32),
                 ("nrow_blocks", C.c_uint32), ("ncuts", C.c_uint32), ("uniform_rows", C.c_uint32), ("row_cut", C.c_uint32 * 33),
-                ("workgroups", C.c_uint32), ("short_kernel", C.c_uint32)]
+                ("workgroups", C.c_uint32), ("resident_kernel", C.c_uint32), ("walk_slots", C.c_uint32), ("walk_rounds", C.c_uint32),
+                ("walk_len", C.c_uint32 * 8), ("walk_base", C.c_uint32 * 8)]
 
 
 def launch_plan(nsymbols: int, nrows: int, shard_index: int = 0, shard_count: int = 1, wave_slots: int = 0, tuning=()):
     """How a launch of this shape hands out its tiles (include/havac_dev.h: havac_ssv_plan; no device needed) -> dict with
     the partitions, the grouping of short models' tiles, the row blocks of cut tiles, and `items`: per partition the list of
-    (first tile of the launch, tiles walked, row block or None) in the order its workgroups take them."""
+    (first tile of the launch, tiles walked, row block or None) in the order its workgroups take them -- for a launch of the
+    resident-table kernel (short models) one "partition" with one item per wave: its run of adjacent tiles."""
     plan = _LaunchPlan()
     arr = (C.c_int32 * max(1, len(tuning)))(*[int(v) for v in tuning])
     rc = _lib.load().havac_ssv_plan(nsymbols, nrows, shard_index, shard_count, wave_slots, arr, len(tuning), C.byref(plan))
     if rc != 0:
         raise_for(rc, "no plan for this shape / tuning")
-    out = {name: getattr(plan, name) for name, _ in _LaunchPlan._fields_ if name not in ("part_begin", "row_cut")}
+    out = {name: getattr(plan, name) for name, _ in _LaunchPlan._fields_ if name not in ("part_begin", "row_cut", "walk_len", "walk_base")}
+    out["walk_len"] = list(plan.walk_len)[: plan.walk_rounds] if plan.resident_kernel else []
+    out["walk_base"] = list(plan.walk_base)[: plan.walk_rounds] if plan.resident_kernel else []
     out["part_begin"] = list(plan.part_begin)[: plan.nparts + 1]
     cuts = list(plan.row_cut)[: plan.ncuts + 1]
     blocks = [(cuts[b], cuts[b + 1]) for b in range(plan.ncuts)]
@@ -180,6 +184,16 @@ def launch_plan(nsymbols: int, nrows: int, shard_index: int = 0, shard_count: in
         at += plan.uniform_rows
     out["row_blocks"] = blocks if plan.nrow_blocks > 1 else []
     items = []
+    if plan.resident_kernel:
+        runs = []
+        for g in range(plan.workgroups * 4):
+            r = min(g // plan.walk_slots, plan.walk_rounds - 1)
+            first = plan.walk_base[r] + (g - r * plan.walk_slots) * plan.walk_len[r]
+            first, end = min(first, plan.ntiles), min(first + plan.walk_len[r], plan.ntiles)
+            if end > first:
+                runs.append((first, end - first, None))
+        out["items"] = [runs]
+        return out
     for k in range(plan.nparts):
         t0, t1 = plan.part_begin[k], plan.part_begin[k + 1]
         mine = t1 - t0

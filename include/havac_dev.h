@@ -325,7 +325,10 @@ typedef struct havac_launch_plan {
     uint32_t tiles_per_group, single_tiles, cut_tiles;
     uint32_t nrow_blocks, ncuts, uniform_rows, row_cut[33];
     uint32_t workgroups;
-    uint32_t short_kernel;   /* 1: the launch runs the short-model instantiation of the kernel (havac_ssv_set_kernel_variant) */
+    uint32_t resident_kernel;   /* 1: the launch runs ssv_resident_kernel (short models; havac_ssv_set_kernel_variant): `workgroups` x 4 waves
+                                   in walk_rounds rounds of walk_slots waves (the last round: the rest); wave i of round r walks
+                                   walk_len[r] adjacent tiles from tile walk_base[r] + i * walk_len[r] on, clipped to ntiles */
+    uint32_t walk_slots, walk_rounds, walk_len[8], walk_base[8];
 } havac_launch_plan;
 int havac_ssv_plan(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index, uint32_t shard_count, uint32_t wave_slots,
                    const int32_t *tuning, uint32_t ntuning, havac_launch_plan *plan_out);

@@ -187,14 +187,14 @@ def test_ssv_kernel_resources():
     assert hot["private_segment_fixed_size"] == 0, hot       # no scratch
     assert hot["sgpr_spill_count"] == 0 and hot["vgpr_spill_count"] == 0, hot
     assert hot["group_segment_fixed_size"] <= 160 * 1024 // 6, hot      # six workgroups per CU fit the LDS
-    # the short-model instantiation of the same body (round 4): five waves per SIMD = 96 VGPRs (512 / 5 = 102 in granules of 8),
-    # of which eight carry the next tile's first loads across a tile; no scratch either
-    short = [v for k, v in kernels.items() if "21ssv_diag_kernel_short" in k]
+    # the resident-table kernel for short models (round 4): the same windows, six waves per SIMD too, no scratch either; its nine
+    # tables (25 KB per workgroup) leave room for six workgroups per CU
+    short = [v for k, v in kernels.items() if "19ssv_resident_kernel" in k]
     assert len(short) == 1, sorted(kernels)
     short = short[0]
-    assert 80 < short["vgpr_count"] <= 96, short
+    assert short["vgpr_count"] <= 80, short
     assert short["private_segment_fixed_size"] == 0 and short["sgpr_spill_count"] == 0 and short["vgpr_spill_count"] == 0, short
-    assert short["group_segment_fixed_size"] <= 160 * 1024 // 5, short
+    assert short["group_segment_fixed_size"] <= 160 * 1024 // 6, short
     assert any("ssv_diag_kernel_traced" in k for k in kernels) and any("ssv_gather_tails" in k for k in kernels)
     # The ordering kernels that touch every record (hit_order.hip.h) fit into the 32 VGPRs the SSV kernel leaves free on a SIMD
     # (512 - 6 x 80): a pass's ordering then runs in the shadow of the next pass's kernel instead of displacing its waves.
@@ -242,8 +242,10 @@ def test_ssv_kernel_instruction_mix(tmp_path):
     assert asm_chunk.total(chunk, ("scratch_",)) == 0 and asm_chunk.total(chunk, ("v_readlane", "v_writelane")) == 0, dict(chunk)
     # the hit test: one OR tree + one compare per four-step window, on the vector unit; everything else of a window is adds
     assert chunk["v_or3_b32"] + chunk["v_bitop3_b32"] + chunk["v_cmp_ne_u32_e64"] <= 72, dict(chunk)
-    # the short-model instantiation runs the same windows (a few more moves around them: the next tile's loads live in registers)
-    short = asm_chunk.chunk_mix(isa, "_ZN5havac21ssv_diag_kernel_short")
+    # the resident-table kernel runs the same windows and builds no table inside a chunk (its register allocation is as easy to
+    # upset as the standard kernel's: a tile loop written without the lambda around a tile's body moved 130-160 registers per
+    # chunk and spilled, at 30.5 instead of 39.8 TCUPS on 32 rows)
+    short = asm_chunk.chunk_mix(isa, "_ZN5havac19ssv_resident_kernel")
     assert short["chunk"]["v_pk_add_i16"] == 512 and short["windows"]["ds_read_b64"] == 256, dict(short["chunk"])
-    assert asm_chunk.total(short["windows"], ("v_",)) == asm_chunk.total(windows, ("v_",)), (dict(short["windows"]), dict(windows))
-    assert asm_chunk.total(short["chunk"], ("v_",)) <= 632 and asm_chunk.total(short["chunk"], ("scratch_",)) == 0, dict(short["chunk"])
+    assert asm_chunk.total(short["chunk"], ("v_",)) <= 625 and asm_chunk.total(short["chunk"], ("scratch_",)) == 0, dict(short["chunk"])
+    assert short["chunk"].get("v_perm_b32", 0) == 0 and asm_chunk.total(short["chunk"], ("ds_write",)) == 0, dict(short["chunk"])

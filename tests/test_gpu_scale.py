@@ -320,17 +320,18 @@ def test_passes_in_flight_give_the_same_lists(torch_dev, oracle):
         assert want.size > 0 and np.array_equal(mine, want)
 
 
-@pytest.mark.parametrize("nrows", [32, 64, 100])
+@pytest.mark.parametrize("nrows", [32, 64, 100, 256])
 def test_short_models_whole_hit_list(torch_dev, oracle, nrows):
-    """Short single models x 100 Mbp (tiles of one to four chunks, 12,209 blocks that end within microseconds of each
-    other and leave their records through the block tails); the whole hit list against the checker."""
+    """Short single models x 100 Mbp: the resident-table kernel (1,536 workgroups, every wave walks 7 or 8 adjacent tiles, the
+    model's tables built once per workgroup) and the standard kernel (tiles of one to eight chunks, 12,209 blocks that end within
+    microseconds of each other and leave their records through the block tails); the whole hit list against the checker."""
     torch, dev = torch_dev
     ncols = 100_012_032
     model, cons = synth.dfam_like_model(nrows, 4242 + nrows)
     packed = synth.random_packed(ncols, 4243)
     ran = []
     got, = run_shards(torch, dev, packed, model, variants_run=ran)
-    assert ran == [1]                    # the short-model kernel (round 4): five waves per SIMD, walks of four tiles, loads a tile ahead
+    assert ran == [1]                    # the resident-table kernel (round 4)
     assert got.size > 1000
     want = whole_list(oracle, packed, model)
     assert np.array_equal(got, want)
@@ -340,21 +341,22 @@ def test_short_models_whole_hit_list(torch_dev, oracle, nrows):
     if nrows == 64:
         again, = run_shards(torch, dev, packed, model, tuning=dict(tiles_per_item=-4), variant=0)
         assert np.array_equal(again, want)
-        # the short-model kernel with other walks: every tile a walk of its own (loads never ahead), long walks without single tiles
-        for walk in (1, 2, 7, -3):
+        # the resident-table kernel with other runs: every tile a wave of its own, runs of 2 and of 50 tiles
+        for walk in (1, 2, 50):
             again, = run_shards(torch, dev, packed, model, tuning=dict(tiles_per_item=walk), variant=1, variants_run=ran)
             assert ran[-1] == 1 and np.array_equal(again, want), walk
 
 
 def test_short_model_kernel_on_small_ragged_problems(torch_dev, oracle):
-    """ssv_diag_kernel_short where its prefetch meets the matrix's edges: a handful of tiles (the first tile's diagonals start
-    left of column 0, the last one's end right of column N), one-row and 128-row models, tile counts that are no multiple of the
-    walk, dense-hit models (two-step windows), sharded runs (every shard walks its own tiles), and the cases it must NOT
-    take: 129 rows, a separator mask (boundary mode) -- the library's choice falls back to the standard kernel."""
+    """ssv_resident_kernel where its runs and its prefetch meet the matrix's edges: a handful of tiles (the first tile's diagonals
+    start left of column 0, the last one's end right of column N), one-row and 256-row models (one to nine tables), runs of 1 to
+    8 tiles and tile counts that are no multiple of the run, dense-hit models (two-step windows), sharded runs (every shard
+    walks its own tiles), and the cases it must NOT take: 257 rows, a separator mask (boundary mode: test_gpu_boundary_mode.py)
+    -- the library's choice falls back to the standard kernel."""
     torch, dev = torch_dev
     rng = np.random.default_rng(404)
     for case in range(24):
-        nrows = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 96, 100, 127, 128]))
+        nrows = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 96, 100, 127, 128, 129, 200, 255, 256]))
         nseg = int(rng.integers(1, 9))
         sym = synth.random_symbols(nseg * synth.SEGMENT, 150 + case)
         if case % 4 == 0:
@@ -362,7 +364,7 @@ def test_short_model_kernel_on_small_ragged_problems(torch_dev, oracle):
         else:
             model, cons = synth.dfam_like_model(nrows, 160 + case)
             synth.plant_homologs(sym, cons, sym.size, every=700, length=min(nrows, 150), sub=0.08)
-        walk = int(rng.choice([-1, 1, 2, 3, 4, 8, -2, -4]))
+        walk = int(rng.choice([-1, 1, 2, 3, 4, 8, 5, 7]))
         ran = []
         got, = run_shards(torch, dev, synth.pack_2bit(sym), model, capacity=1 << 23, tuning=dict(tiles_per_item=walk), variant=1, variants_run=ran)
         want = oracle.ssv(sym, model, cap=1 << 23)
@@ -373,10 +375,10 @@ def test_short_model_kernel_on_small_ragged_problems(torch_dev, oracle):
     ran = []
     parts = run_shards(torch, dev, synth.pack_2bit(sym), model, world=4, variants_run=ran)
     assert ran == [1, 1, 1, 1] and np.array_equal(np.concatenate(parts), oracle.ssv(sym, model))
-    model129, _ = synth.dfam_like_model(129, 197)
+    model257, _ = synth.dfam_like_model(257, 197)
     ran = []
-    got, = run_shards(torch, dev, synth.pack_2bit(sym), model129, variant=1, variants_run=ran)
-    assert ran == [0] and np.array_equal(got, oracle.ssv(sym, model129))
+    got, = run_shards(torch, dev, synth.pack_2bit(sym), model257, variant=1, variants_run=ran)
+    assert ran == [0] and np.array_equal(got, oracle.ssv(sym, model257))
 
 
 @pytest.mark.parametrize("per_item", [2, 3, 8])

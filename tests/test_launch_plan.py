@@ -73,18 +73,27 @@ def test_the_rules_on_the_baseline_shapes():
     assert sizes[0] > sizes[3] * 1.15 and sizes[-1] > sizes[3] * 1.15                              # partitions of equal work: the two ends hold more (shorter) tiles
     c5 = launch_plan(100_012_032, 20_000)
     assert c5["row_blocks"] == [(0, 10240), (10240, 15360), (15360, 20000)] and c5["cut_tiles"] == 1152    # 1.5 rounds of 6144 slots over 8 partitions
-    # short models (round 4): the short-model kernel -- five waves per SIMD, 5120 wave slots -- walks groups of four tiles, a
-    # partition's last round of wave slots as single tiles; the standard kernel (variant 0) keeps single tiles
+    # short models (round 4): the resident-table kernel -- every wave walks a run of adjacent tiles; the runs come in rounds of as many
+    # waves as the chip holds and taper (9/16 of what is left per slot), the last rounds are single tiles; the standard kernel
+    # (variant 0) keeps single tiles throughout
     short = launch_plan(100_012_032, 32)
-    assert short["short_kernel"] == 1 and short["tiles_per_group"] == 4 and short["single_tiles"] == 640 and short["nrow_blocks"] == 1
-    assert all(sum(1 for _, w, _ in p if w == 1) >= 640 and sum(1 for _, w, _ in p if w == 4) > 1000 for p in short["items"])
-    assert launch_plan(100_012_032, 128)["short_kernel"] == 1 and launch_plan(100_012_032, 129)["short_kernel"] == 0
+    assert short["resident_kernel"] == 1 and short["walk_slots"] == 6144 and short["walk_len"] == [4, 2, 1] and short["nrow_blocks"] == 1
+    assert short["walk_base"] == [0, 4 * 6144, 6 * 6144]
+    runs = short["items"][0]
+    assert [w for _, w, _ in runs[:6144]] == [4] * 6144 and [w for _, w, _ in runs[6144:2 * 6144]] == [2] * 6144 and {w for _, w, _ in runs[2 * 6144:]} == {1}
+    assert short["workgroups"] == 2 * 1536 + -(-(short["ntiles"] - 6 * 6144) // 4)
+    assert launch_plan(100_012_032, 256)["resident_kernel"] == 1 and launch_plan(100_012_032, 257)["resident_kernel"] == 0
+    few = launch_plan(SEG, 40)                         # fewer tiles than wave slots: one tile per wave, no empty workgroups but the last
+    assert few["resident_kernel"] == 1 and few["workgroups"] == (few["ntiles"] + 3) // 4 and few["walk_len"] == [1]
+    forced = launch_plan(100_012_032, 32, tuning=(-1, 50, -1, -1, -1, -1, -1, -1, 1))       # tests: runs of a given length throughout
+    assert forced["walk_len"] == [50] and forced["workgroups"] == -(-(-(-forced["ntiles"] // 50)) // 4)
     std = launch_plan(100_012_032, 32, tuning=(-1, -1, -1, -1, -1, -1, -1, -1, 0))
-    assert std["short_kernel"] == 0 and std["tiles_per_group"] == 1 and std["nrow_blocks"] == 1
+    assert std["resident_kernel"] == 0 and std["tiles_per_group"] == 1 and std["nrow_blocks"] == 1
+    assert launch_plan(100_012_032, 32, tuning=(-1, 4))["resident_kernel"] == 0          # a forced work distribution is the standard kernel's
     walk = launch_plan(100_012_032, 32, tuning=(-1, -4, -1, -1, -1, -1, -1, -1, 0))
     assert walk["tiles_per_group"] == 4 and walk["single_tiles"] == 768
     assert all(sum(1 for _, w, _ in p if w == 1) >= 768 and sum(1 for _, w, _ in p if w == 4) > 1000 for p in walk["items"])
-    assert c2["short_kernel"] == 0 and c5["short_kernel"] == 0
+    assert c2["resident_kernel"] == 0 and c5["resident_kernel"] == 0
 
 
 def test_refusals():
