@@ -1153,8 +1153,14 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         fetch_symbols(p_begin + 32, z, mine.lane8);
         // The global loads of a chunk (12 B of model rows and 8 B of symbols per lane) are issued at the END of the chunk
         // before it and consumed at its top: no register carries them across the windows, and the latency that is
-        // exposed this way is covered by the other four waves of the SIMD (measured in round 1: 2.12 ms against 2.16 ms
-        // with the loads issued a whole chunk ahead).
+        // exposed this way is covered by the other five waves of the SIMD -- mostly: by an ablation (round 4; no loads, wrong
+        // results) the two trips to memory per chunk cost 4.4 % of the kernel at 1024 rows (rows 2.0 %, symbols 2.4 %).
+        // Neither cure kept: staged through LDS by LDS-DMA a whole chunk ahead (five global_load_lds_dword per chunk, picked up
+        // with five add-TID reads; correct, 46 parity tests) the kernel was 2 % SLOWER -- an LDS-DMA instruction costs the wave
+        // more issue time than the wait it saves; the symbols loaded in front of window 5 into the two prepared words that are
+        // dead by then ended in hipcc's "illegal VGPR to SGPR copy" (DESIGN.md section 7b).  The model's rows kept in LDS by the
+        // workgroup (a chunk's three rows then come with an LDS read): no change at all, 1.752 against 1.749 ms -- the wait at
+        // a chunk's end is the symbols'; what the ablation's "rows" share really is, is the table build itself.
 
         bool go_on = true;                 // wave-uniform
         // one bit per chunk: may the chunk look for hits every four steps only (ssv_prepare_model)?  never with separators.

@@ -223,7 +223,7 @@ def test_ssv_kernel_instruction_mix(tmp_path):
     """The hot loop's instruction mix, asserted from the disassembly (the register allocation at exactly
     80 VGPRs is one unrelated edit away from breaking, and VGPR count / scratch alone do not show a loop that got longer).
     One 32-step chunk on its usual path -- no matrix edge, four-step windows, no hit -- is 16 registers x 32 steps = 512
-    `v_pk_add_i16 ... clamp` and at most 620 vector instructions in all (72 for the hit tests, 15
+    `v_pk_add_i16 ... clamp` and at most 628 vector instructions in all (72 for the hit tests, 15
     window expansions, 5 `v_perm` + a handful for the tables); 256 `ds_read_b64` in the windows; nothing from scratch."""
     import importlib.util
     import shutil
@@ -237,7 +237,7 @@ def test_ssv_kernel_instruction_mix(tmp_path):
     chunk, windows = mix["chunk"], mix["windows"]
     valu = asm_chunk.total(chunk, ("v_",))
     assert chunk["v_pk_add_i16"] == 512, dict(chunk)
-    assert valu <= 620, (valu, {k: n for k, n in chunk.items() if k.startswith("v_")})
+    assert valu <= 628, (valu, {k: n for k, n in chunk.items() if k.startswith("v_")})      # (619 + the 8 moves of the window's slide, counted since round 4)
     assert windows["ds_read_b64"] == 256, dict(windows)
     assert asm_chunk.total(chunk, ("scratch_",)) == 0 and asm_chunk.total(chunk, ("v_readlane", "v_writelane")) == 0, dict(chunk)
     # the hit test: one OR tree + one compare per four-step window, on the vector unit; everything else of a window is adds

@@ -16,6 +16,7 @@ sys.setrecursionlimit(100000)
 DEFAULT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "asm2",
                        "havac_dev-hip-amdgcn-amd-amdhsa-gfx950.s")
 NEAR = 60          # lines: a rare block is shorter than this
+BACK = 40          # lines: the back edge lands on the loop header or on a block this close in front of it (it falls into the header)
 
 
 def chunk_mix(path=DEFAULT, kernel="_ZN5havac15ssv_diag_kernel", verbose=False):
@@ -35,12 +36,14 @@ def chunk_mix(path=DEFAULT, kernel="_ZN5havac15ssv_diag_kernel", verbose=False):
             return label_at.get(t.split()[-1])
         return None
 
-    # the chunk loop's back edge: the last branch behind the windows that goes to the header (or to a block that falls into it)
-    back_edges = [i for i in range(after_windows, len(body)) if (branch_target(i) or 0) and header - 15 <= branch_target(i) <= header]
+    # the chunk loop's back edge: the last branch behind the windows that goes to the header (or to a block that falls into it);
+    # that block is where the usual path starts
+    back_edges = [i for i in range(after_windows, len(body)) if (branch_target(i) or 0) and header - BACK <= branch_target(i) <= header]
     loop_end = back_edges[0]
     for i in back_edges:
         if i - loop_end < 400:
             loop_end = i
+    loop_top = min(branch_target(i) for i in back_edges if i <= loop_end)
 
     def instruction(i):
         t = body[i].split(";")[0].strip()
@@ -67,9 +70,9 @@ def chunk_mix(path=DEFAULT, kernel="_ZN5havac15ssv_diag_kernel", verbose=False):
             op = t.split()[0]
             if op == "s_branch" or op.startswith("s_cbranch"):
                 target = label_at.get(t.split()[-1])
-                if target is not None and header - 15 <= target <= header:
+                if target is not None and loop_top <= target <= header and i > after_windows:
                     break                                                # the back edge
-                if target is not None and target < header - 15 and op == "s_branch":
+                if target is not None and target < loop_top and op == "s_branch":
                     return 10 ** 9, path_here                            # out of the loop
                 if target is not None and op == "s_branch":
                     i = target
@@ -86,7 +89,7 @@ def chunk_mix(path=DEFAULT, kernel="_ZN5havac15ssv_diag_kernel", verbose=False):
         mine = sum(1 for k in path_here if instruction(k).startswith("v_"))
         return mine, path_here
 
-    _, usual = best(header + 1)
+    _, usual = best(loop_top + 1)
     per_region = collections.defaultdict(collections.Counter)
     for k in usual:
         region = "prologue" if k < first_window else ("windows" if k < after_windows else "epilogue")
