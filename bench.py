@@ -189,10 +189,10 @@ def measure_traffic(args):
             for path in glob.glob(os.path.join(out, "**", f"*{counter.lower()}*counter_collection.csv"), recursive=True):
                 with open(path) as f:
                     for row in csv.DictReader(f):
-                        if "ssv_diag_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        if ("ssv_diag_kernel" in row["Kernel_Name"] or "ssv_resident_kernel" in row["Kernel_Name"]) and row["Counter_Name"] == counter:
                             per_dispatch[row["Dispatch_Id"]] = per_dispatch.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
             if not per_dispatch:
-                return None, f"no ssv_diag_kernel rows in the {counter} pass"
+                return None, f"no ssv_diag_kernel / ssv_resident_kernel rows in the {counter} pass"
             values[counter] = sum(per_dispatch.values()) / len(per_dispatch)
     except subprocess.TimeoutExpired:
         return None, "rocprofv3 --pmc pass timed out"

@@ -165,7 +165,10 @@ RowCuts plan_row_cuts(uint32_t nrows_padded, uint32_t short_rows, uint32_t guide
 //    ssv_resident_kernel: as many workgroups as the chip holds at once, the model's tables built once per workgroup and kept
 //    in LDS, every wave walks its own run of adjacent tiles -- runs of equal length (+- one tile), dealt by the wave's number
 //    alone (ssv_kernels.hip.h, "the resident-table variant").  No partitions, no tickets, no cut tiles, no block tails.
-constexpr uint64_t kWalkShareX16 = 9;      // resident-table launches: a round's runs take 9/16 of the tiles that are left per wave slot
+#ifndef HAVAC_WALK_SHARE_X16
+#define HAVAC_WALK_SHARE_X16 12
+#endif
+constexpr uint64_t kWalkShareX16 = HAVAC_WALK_SHARE_X16;      // resident-table launches: a round's runs take 12/16 of the tiles that are left per wave slot
 struct PlanTuning { int rows_per_block, tiles_per_item, parts_log2; uint32_t split_rounds_x4, short_rows, guide; int variant = -1; };
 struct LaunchPlan { SsvRare L{}; uint32_t nblocks = 0, largest_item_rows = 0; bool resident_kernel = false; };
 // which kernel runs a launch: the resident-table one where the model is short and nothing it leaves out is asked for (separator
@@ -187,7 +190,7 @@ int plan_launch(std::string& err, const Tiling& t, uint32_t tb, uint32_t te, int
         // starts a round's workgroups as the slots of the round before come free).  A SIMD serves its oldest wave first, so the
         // waves of a round do not end together but one after the other; equal runs in ONE round left the SIMDs with five, four,
         // ... one wave over the last 60 % of the launch (50 TCUPS at 256 rows where single tiles run at 56).  So the runs taper:
-        // a round takes kWalkShare of what is left per slot, the last rounds are single tiles -- a workgroup's start, its tables
+        // a round takes 3/4 (kWalkShareX16: 9/16 and 14/16 measured within 1 %) of what is left per slot, the last rounds are single tiles -- a workgroup's start, its tables
         // and its end are paid ~3 times per slot instead of once per tile, and the launch still ends within a tile's time.
         // (tests: tiles_per_item = G >= 1 asks for runs of G tiles throughout, so that small problems walk too)
         const uint64_t nslots = std::max<uint64_t>(kWavesPerBlock, slots / kWavesPerBlock * kWavesPerBlock);

@@ -1370,25 +1370,31 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
         prepare_symbols(z, w.x, w.y);
     };
     // a tile's first diagonal and the first of its rows that can lie inside the matrix (ssv_diag_body: d0, p_lo)
+    // (the launch's tiling is read ONCE: this kernel has scalar registers to spare -- 77 -- and a tile of one chunk has no time
+    // for three kernarg loads in a row)
+    const int64_t tiling_diag0 = rare_args()->first_diag + (int64_t)rare_args()->tile_begin * kTileDiags, tiling_col_end = rare_args()->col_end;
     auto tile_start = [&](const uint32_t t, int64_t& d0, uint32_t& p_lo) {
-        const rare_args_t launch = rare_args();
-        d0 = launch->first_diag + (int64_t)(launch->tile_begin + t) * kTileDiags;
+        d0 = tiling_diag0 + (int64_t)t * kTileDiags;
         int64_t lo64 = -d0 - kTileDiags;
         if (lo64 < 0) lo64 = 0;
         if (lo64 > (int64_t)nrows_padded) lo64 = nrows_padded;
         p_lo = __builtin_amdgcn_readfirstlane((uint32_t)lo64);
     };
-    // A tile's first loads, all in flight before anything waits: the symbols of its first two chunks and the abort word (read
-    // past the caches; it travels with the symbols).  The ranges are recomputed where the words are consumed -- scalar
-    // arithmetic -- so that only the loaded words are carried.
-    auto issue_tile_loads = [&](const uint32_t t, TileSymbols& L) {
+    // A tile's first loads, all in flight before anything waits: the symbols of its first two chunks and, for a run's first tile,
+    // the abort word (read past every cache: a trip of microseconds, as long as a whole one-chunk tile -- once per run, which
+    // is at most a few dozen microseconds long, is often enough).  The ranges are recomputed where the words are consumed --
+    // scalar arithmetic -- so that only the loaded words are carried.
+    auto issue_tile_loads = [&](const uint32_t t, TileSymbols& L, const bool with_abort_word) {
         int64_t t_d0; uint32_t t_lo;
         tile_start(t, t_d0, t_lo);
         const uint32_t lane8 = fresh_lane() * 8u;
         L.w0 = load_symbols(symbol_range(t_d0 + t_lo), lane8);
         L.w1 = load_symbols(symbol_range(t_d0 + t_lo + 32), lane8);
-        const uint32_t* const abort_flag = rare_args()->abort_flag;
-        L.abort_word = abort_flag ? __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+        L.abort_word = 0;
+        if (with_abort_word) {
+            const uint32_t* const abort_flag = rare_args()->abort_flag;
+            L.abort_word = abort_flag ? __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+        }
     };
 
     TileSymbols ahead{};               // the first loads of the run's NEXT tile, in flight across the end of the current one
@@ -1396,7 +1402,7 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
         const uint32_t tile = __builtin_amdgcn_readfirstlane(tile_arg), more = __builtin_amdgcn_readfirstlane(more_arg);
         int64_t d0; uint32_t p_lo;
         tile_start(tile, d0, p_lo);
-        int64_t hi64 = rare_args()->col_end - d0;                                  // first row entirely right of the shard's columns
+        int64_t hi64 = tiling_col_end - d0;                                        // first row entirely right of the shard's columns
         if (hi64 > (int64_t)nrows_padded) hi64 = nrows_padded;
         if (hi64 < 0) hi64 = 0;
         const uint32_t p_hi = __builtin_amdgcn_readfirstlane((uint32_t)hi64);
@@ -1404,10 +1410,10 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
         // (`ahead` is written on every path: kept conditionally, its OLD words would stay alive through the chunk loop)
         ahead = TileSymbols{};
         if (p_lo >= p_hi) {                                              // (a tile without rows: never expected inside a launch's range)
-            if (more) issue_tile_loads(tile + 1, ahead);
+            if (more) issue_tile_loads(tile + 1, ahead, false);
             return true;
         }
-        if (__builtin_amdgcn_readfirstlane(now.abort_word)) return false;       // abort: a device word, looked at once per tile
+        if (__builtin_amdgcn_readfirstlane(now.abort_word)) return false;       // abort: a device word, looked at once per run
         uint32_t x[kRegs], x2[kRegs];     // the scores and their ping-pong partner (see step_window)
 #pragma unroll
         for (int i = 0; i < kRegs; i++) x[i] = x2[i] = kScoreZero;
@@ -1431,7 +1437,7 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
         }
         // the next tile's first loads: in flight across the step behind the last chunk and the next tile's scalar prologue
         // (issued here, not inside the chunk loop: nothing of them is alive through the windows)
-        if (more) issue_tile_loads(tile + 1, ahead);
+        if (more) issue_tile_loads(tile + 1, ahead, false);
         if (p_hi == nrows_padded) {
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
@@ -1443,34 +1449,8 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
     const uint64_t clock_start = __builtin_readcyclecounter() * 0 + wall_clock64();
     const uint32_t tiles_mine = tile_end - tile;
 #endif
-    if (tile < tile_end) issue_tile_loads(tile, ahead);
-#ifdef HAVAC_RESIDENT_STAGGER
-    {   // experiment: the waves of a SIMD (one of each of the CU's six workgroups) and the SIMDs of a CU start out of step
-        const uint32_t slot = (blockIdx.x / 256u) % 6u, units = slot * 4u + wave;      // 0..23
-        for (uint32_t k = 0; k < units; k++) __builtin_amdgcn_s_sleep(HAVAC_RESIDENT_STAGGER);
-    }
-#endif
-#ifdef HAVAC_RESIDENT_ROTATE
-    const uint32_t first_of_run = tile;
-    uint32_t turn;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(turn));       // the wave's slot on its SIMD
-#endif
+    if (tile < tile_end) issue_tile_loads(tile, ahead, true);
     for (; tile < tile_end; tile++) {
-#ifdef HAVAC_RESIDENT_ROTATE
-        // The instruction arbiter serves the OLDEST wave of a SIMD first: left alone, the six waves of a SIMD run their equal
-        // runs almost one after the other (the first leaves after 40 % of the launch, the last runs alone at the end).  Every
-        // wave therefore takes turns at the four priority levels, a tile at a time, offset by its slot.
-#if HAVAC_RESIDENT_ROTATE == 2
-        // by what is left of the run: a wave that is ahead of its siblings drops a level and lets them catch up
-        turn = ((tile_end - tile) * 4u - 1u) / (tile_end - first_of_run);
-#endif
-        switch (turn++ & 3u) {
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            case 2: __builtin_amdgcn_s_setprio(2); break;
-            default: __builtin_amdgcn_s_setprio(3); break;
-        }
-#endif
         if (!run_tile(tile, tile + 1 < tile_end ? 1u : 0u)) break;
     }
 #ifdef HAVAC_WAVE_CLOCKS

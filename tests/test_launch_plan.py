@@ -74,14 +74,14 @@ def test_the_rules_on_the_baseline_shapes():
     c5 = launch_plan(100_012_032, 20_000)
     assert c5["row_blocks"] == [(0, 10240), (10240, 15360), (15360, 20000)] and c5["cut_tiles"] == 1152    # 1.5 rounds of 6144 slots over 8 partitions
     # short models (round 4): the resident-table kernel -- every wave walks a run of adjacent tiles; the runs come in rounds of as many
-    # waves as the chip holds and taper (9/16 of what is left per slot), the last rounds are single tiles; the standard kernel
+    # waves as the chip holds and taper (3/4 of what is left per slot), the last rounds are single tiles; the standard kernel
     # (variant 0) keeps single tiles throughout
     short = launch_plan(100_012_032, 32)
-    assert short["resident_kernel"] == 1 and short["walk_slots"] == 6144 and short["walk_len"] == [4, 2, 1] and short["nrow_blocks"] == 1
-    assert short["walk_base"] == [0, 4 * 6144, 6 * 6144]
+    assert short["resident_kernel"] == 1 and short["walk_slots"] == 6144 and short["walk_len"] == [5, 2, 1] and short["nrow_blocks"] == 1
+    assert short["walk_base"] == [0, 5 * 6144, 7 * 6144]
     runs = short["items"][0]
-    assert [w for _, w, _ in runs[:6144]] == [4] * 6144 and [w for _, w, _ in runs[6144:2 * 6144]] == [2] * 6144 and {w for _, w, _ in runs[2 * 6144:]} == {1}
-    assert short["workgroups"] == 2 * 1536 + -(-(short["ntiles"] - 6 * 6144) // 4)
+    assert [w for _, w, _ in runs[:6144]] == [5] * 6144 and [w for _, w, _ in runs[6144:2 * 6144]] == [2] * 6144 and {w for _, w, _ in runs[2 * 6144:]} == {1}
+    assert short["workgroups"] == 2 * 1536 + -(-(short["ntiles"] - 7 * 6144) // 4)
     assert launch_plan(100_012_032, 256)["resident_kernel"] == 1 and launch_plan(100_012_032, 257)["resident_kernel"] == 0
     few = launch_plan(SEG, 40)                         # fewer tiles than wave slots: one tile per wave, no empty workgroups but the last
     assert few["resident_kernel"] == 1 and few["workgroups"] == (few["ntiles"] + 3) // 4 and few["walk_len"] == [1]

@@ -12,7 +12,7 @@ for path in sorted(glob.glob(os.path.join(root, "*counter_collection.csv"))):
     per = collections.defaultdict(lambda: collections.defaultdict(float))   # counter -> dispatch -> value
     with open(path) as f:
         for row in csv.DictReader(f):
-            if "ssv_diag_kernel" not in row["Kernel_Name"]:
+            if not ("ssv_diag_kernel" in row["Kernel_Name"] or "ssv_resident_kernel" in row["Kernel_Name"]):
                 continue
             per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
     for counter in sorted(per):

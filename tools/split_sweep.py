@@ -26,7 +26,7 @@ def counter(name, tuning, tag):
     per = {}
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if "ssv_diag_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == name:
+            if ("ssv_diag_kernel" in row.get("Kernel_Name", "") or "ssv_resident_kernel" in row.get("Kernel_Name", "")) and row.get("Counter_Name") == name:
                 per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
     shutil.rmtree(out, ignore_errors=True)
     return sum(per.values()) / len(per) if per else float("nan")
