@@ -40,5 +40,15 @@ for w in ("c2", "c3", "c5"):
         print(f"profiles/{dst_tag}_pmc_{w}.csv")
 copy(f"{src_tag}_bench_c4_one_gpu.json", f"{dst_tag}_bench_c4_one_gpu.json")
 copy(f"{src_tag}_rows_sweep.txt", f"{dst_tag}_rows_sweep_kernel_ms.txt")
+copy(f"{src_tag}_rows_sweep_standard_kernel.txt", f"{dst_tag}_rows_sweep_kernel_ms_standard_kernel_forced.txt")
+copy(f"{src_tag}_bench_rows64.json", f"{dst_tag}_bench_rows64.json")
+stats = os.path.join(G, f"{src_tag}_prof_rows64", "rows64_kernel_stats.csv")
+if os.path.isfile(stats):
+    with open(os.path.join(P, f"{dst_tag}_kernel_stats_rows64.csv"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --rows 64 --no-pmc --no-cpu-baseline (MI355X; {note}); kernel names shortened\n")
+        for r in csv.reader(open(stats)):
+            r[0] = r[0].split("(")[0]
+            f.write(",".join(r) + "\n")
+    print(f"profiles/{dst_tag}_kernel_stats_rows64.csv")
 copy(f"{src_tag}_e2e_series.txt", f"{dst_tag}_e2e_series_51Mbp.txt")
 copy(f"{src_tag}_pcie_inclusive_c2.txt", f"{dst_tag}_pcie_inclusive_c2.txt")

@@ -14,6 +14,13 @@ for w in c2 c3 c5; do
 done
 python3 tools/rows_probe.py > gpurun_out/${tag}_rows_sweep.txt 2>/dev/null
 cat gpurun_out/${tag}_rows_sweep.txt
+# short models: the standard kernel forced (the sweep above takes the library's choice: the resident-table kernel up to 256 rows),
+# a bench line and the kernel trace of one short model
+python3 tools/rows_probe.py --tuning=-1,-1,-1,-1,-1,-1,-1,-1,0 32 64 96 128 160 192 256 > gpurun_out/${tag}_rows_sweep_standard_kernel.txt 2>/dev/null
+cat gpurun_out/${tag}_rows_sweep_standard_kernel.txt
+python3 bench.py --rows 64 > gpurun_out/${tag}_bench_rows64.json 2> gpurun_out/${tag}_bench_rows64.err || echo "bench rows 64 failed"
+tail -c 300 gpurun_out/${tag}_bench_rows64.json; echo
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_rows64 -o rows64 -- python3 bench.py --rows 64 --no-pmc --no-cpu-baseline > gpurun_out/${tag}_bench_rows64_under_rocprof.json 2> gpurun_out/${tag}_prof_rows64.err || echo "rocprof rows 64 failed"
 if [ "$2" = "all" ]; then      # + C4 on one GPU (a 9 s launch per pass), the end-to-end series, the PCIe-inclusive rate
     python3 bench.py --workload c4 --no-pmc > gpurun_out/${tag}_bench_c4_one_gpu.json 2> gpurun_out/${tag}_bench_c4.err || echo "bench c4 failed"
     tail -c 300 gpurun_out/${tag}_bench_c4_one_gpu.json; echo
