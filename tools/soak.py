@@ -32,7 +32,7 @@ for case in range(cases):
     if big:
         nseg = int(rng.integers(50, 2500))
         n = nseg * synth.SEGMENT
-        nrows = int(rng.choice([100, 1024, 2047, 2048, 2049, 5000, 25000, int(rng.integers(1, 12000))]))
+        nrows = int(rng.choice([32, 64, 100, 200, 256, 257, 1024, 2047, 2048, 2049, 5000, 25000, int(rng.integers(1, 300)), int(rng.integers(1, 12000))]))
         kind = int(rng.choice([1, 5]))
     if kind == 0:
         model = rng.integers(-128, 128, size=(nrows, 4)).astype(np.int8)
@@ -56,11 +56,12 @@ for case in range(cases):
     # how the launch hands out its tiles (havac_dev_set_tuning): the library's own rule half of the time, else a random one --
     # partitions or none, how many of the last tiles are cut, finest block, taper; or uniform row blocks for every tile
     tuning = [-1] * 9
-    # which instantiation of the kernel (round 4): the library's choice, or forced -- short models then run the standard kernel,
-    # or the short-model kernel with a random walk length (groups of g tiles; negative: the last round of wave slots single)
+    # which kernel (round 4): the library's choice, or forced -- short models (up to 256 rows) then run the standard kernel (0; with
+    # tiles_per_item: groups of g tiles, negative: the last round of wave slots single), or the resident-table kernel (1; with
+    # tiles_per_item = g >= 1: runs of g tiles throughout instead of tapering rounds)
     tuning[8] = int(rng.choice([-1, -1, 0, 1]))
-    if nrows <= 128 and rng.random() < 0.5:
-        tuning[1] = int(rng.choice([1, 2, 3, 5, 8, -2, -4, -7]))
+    if nrows <= 256 and rng.random() < 0.5:
+        tuning[1] = int(rng.choice([1, 2, 3, 5, 8, 13, -2, -4, -7]))
     pick = rng.random()
     if pick < 0.35:
         tuning[4:8] = [int(rng.choice([0, 1, 2, 3])), int(rng.choice([0, 1, 2, 6, 64])), int(rng.choice([1024, 2048, 4096])), int(rng.choice([2, 3, 4, 16]))]
