@@ -94,19 +94,46 @@ def c_gather(group=None):
     """The process's RcclGather for `group`, made on first use (collective: every rank of the group calls this at the same
     point): rank 0 draws the id, torch.distributed carries it to the others."""
     key = id(group) if group is not None else None
-    g = _c_gathers.get(key)
-    if g is None:
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [RcclGather.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        g = _c_gathers[key] = RcclGather(rank, world, box[0])
+    if key in _c_gathers:
+        return _c_gathers[key]
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    # Every step is agreed on by all ranks before the next one (a MIN all-reduce of "it worked here" through torch.distributed):
+    # a rank that cannot load librccl or make its communicator must not leave the others inside ncclCommInitRank or, later,
+    # inside a gather it never joins.  Where any rank fails, every rank takes torch.distributed's point-to-point route
+    # (gather_hits) for good -- the same exchange, the same buffers.
+    def agreed(ok: bool) -> bool:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return bool(flag.item())
+    g, uid, why = None, None, ""
+    try:
+        uid = RcclGather.unique_id() if rank == 0 else None
+    except Exception as e:      # noqa: BLE001 -- whatever went wrong, the other ranks must hear of it
+        why = str(e)
+    box = [uid]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if agreed(box[0] is not None):
+        try:
+            g = RcclGather(rank, world, box[0])
+        except Exception as e:      # noqa: BLE001
+            why = str(e)
+        if not agreed(g is not None):
+            if g is not None:
+                g.close()
+            g = None
+    if g is None and rank == 0:
+        import sys
+        print(f"havac_amd.dist: the C-ABI gather is not available on every rank ({why or 'another rank failed'}); "
+              "the records travel through torch.distributed's point-to-point operations instead", file=sys.stderr, flush=True)
+    _c_gathers[key] = g
     return g
 
 
 def close_c_gathers():
     """collective (ncclCommDestroy): before the process group goes away"""
     for g in _c_gathers.values():
-        g.close()
+        if g is not None:
+            g.close()
     _c_gathers.clear()
 
 
@@ -140,9 +167,10 @@ def gather_hits(local_hits: torch.Tensor, local_count: int, group=None, out: tor
     `local_count` valid; `local_count` = FAILED if this rank's pass raised).  Returns
     (records concatenated in rank order, per-rank counts) on rank 0 and (None, counts)
     elsewhere.  `out`: optional receive buffer on rank 0 (used when it is large enough)."""
-    if dist.get_backend(group) == "nccl" and os.environ.get("HAVAC_GATHER", "c_abi") != "torch":
+    if dist.get_backend(group) == "nccl" and os.environ.get("HAVAC_GATHER", "c_abi") != "torch" and c_gather(group) is not None:
         # the records travel through libhavac_dev.so's own RCCL calls (HAVAC_GATHER=torch: the same exchange through
-        # torch.distributed's point-to-point operations, kept for comparison)
+        # torch.distributed's point-to-point operations, kept for comparison and taken when the C route cannot be set up
+        # on every rank)
         return _gather_hits_c(local_hits, local_count, group, out)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
