@@ -1153,14 +1153,13 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         fetch_symbols(p_begin + 32, z, mine.lane8);
         // The global loads of a chunk (12 B of model rows and 8 B of symbols per lane) are issued at the END of the chunk
         // before it and consumed at its top: no register carries them across the windows, and the latency that is
-        // exposed this way is covered by the other five waves of the SIMD -- mostly: by an ablation (round 4; no loads, wrong
-        // results) the two trips to memory per chunk cost 4.4 % of the kernel at 1024 rows (rows 2.0 %, symbols 2.4 %).
-        // Neither cure kept: staged through LDS by LDS-DMA a whole chunk ahead (five global_load_lds_dword per chunk, picked up
-        // with five add-TID reads; correct, 46 parity tests) the kernel was 2 % SLOWER -- an LDS-DMA instruction costs the wave
-        // more issue time than the wait it saves; the symbols loaded in front of window 5 into the two prepared words that are
-        // dead by then ended in hipcc's "illegal VGPR to SGPR copy" (DESIGN.md section 7b).  The model's rows kept in LDS by the
-        // workgroup (a chunk's three rows then come with an LDS read): no change at all, 1.752 against 1.749 ms -- the wait at
-        // a chunk's end is the symbols'; what the ablation's "rows" share really is, is the table build itself.
+        // exposed this way is covered by the other five waves of the SIMD.  Round 4 checked that it really is: an ablation
+        // without the two loads and the table build (wrong results) runs 4.4 % faster at 1024 rows, but that is the WORK that
+        // went with them -- with both waits truly removed (the model's rows kept in LDS by the workgroup, the next chunk's
+        // symbols loaded in front of window 5 into registers that are dead by then; correct, 78 GPU tests) the kernel is 1.3 %
+        // SLOWER (1.768-1.774 against 1.747 ms: 633 instead of 627 vector instructions per chunk and four spilled registers),
+        // either one alone changes nothing or costs 1 %, and all five words staged through LDS by LDS-DMA a chunk ahead
+        // cost 2 % (an LDS-DMA instruction costs the wave more issue time than the wait it saves).  DESIGN.md section 7b.
 
         bool go_on = true;                 // wave-uniform
         // one bit per chunk: may the chunk look for hits every four steps only (ssv_prepare_model)?  never with separators.
