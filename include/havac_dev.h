@@ -285,8 +285,9 @@ int havac_ssv_finish_end(havac_ssv_ctx *ctx, uint64_t *hit_count_out);
  * Every value: -1 = the library's own rule (the default).
  *   rows_per_block  > 0: EVERY tile is cut into uniform row blocks of that many rows (a multiple of 1024);
  *                   0 = never cut tiles into row blocks
- *   tiles_per_item  G >= 1: every wave walks a group of G adjacent tiles (short models); G < -1: groups of -G tiles, but a
- *                   partition's last round of wave slots as single tiles
+ *   tiles_per_item  G >= 1: every wave walks a group of G adjacent tiles (short models; standard kernel); G < -1: groups of -G
+ *                   tiles, but a partition's last round of wave slots as single tiles.  Any value but -1 keeps the library from
+ *                   choosing the resident-table kernel by itself (havac_ssv_set_kernel_variant)
  *   block_tails     0 = never, 1 = the default rule, 2 = whatever the height of an item
  *   ordering        0 = always the generic radix sort, 1 = the bucket ordering (the default)
  * No counterpart in the reference. */
@@ -298,13 +299,15 @@ int havac_ssv_set_tuning(havac_ssv_ctx *ctx, int rows_per_block, int tiles_per_i
  *   guide            a row block takes 1 / guide of the rows that are left (2 ... 16; default 2) */
 int havac_ssv_set_split_tuning(havac_ssv_ctx *ctx, int parts_log2, int split_rounds_x4, int short_rows, int guide);
 
-/* Which instantiation of the SSV kernel the next passes run.  -1 (the default): the library decides -- models of up to 128 rows
- * (a tile is one to four 32-row chunks and mostly prologue) take the short-model kernel: five waves per SIMD, every wave walks a
- * group of adjacent tiles with the next tile's first loads in flight across the current one; everything else, and every pass
- * with a separator mask or a cell trace, the standard kernel.  0: always the standard kernel; 1: the short-model kernel wherever
- * it is valid (A/B, tests).  The records are the same either way.  The reference's array runs at the same efficiency whatever
+/* Which SSV kernel the next passes run.  -1 (the default): the library decides -- models of up to 256 (padded) rows take
+ * ssv_resident_kernel: a tile of such a model is one to eight 32-row chunks and, handed out tile by tile, mostly prologue, so
+ * ALL the model's match-word tables are built once per workgroup and kept in LDS, every wave walks a run of adjacent tiles, and
+ * the runs are handed out in tapering rounds (havac_launch_plan: walk_len / walk_base); everything else, and every pass with a
+ * separator mask, a cell trace or a forced work distribution (havac_ssv_set_tuning), takes the standard kernel, ssv_diag_kernel.
+ * 0: always the standard kernel; 1: the resident-table kernel wherever it is valid (A/B, tests; with tiles_per_item = G >= 1:
+ * runs of G tiles throughout).  The records are the same either way.  The reference's array runs at the same efficiency whatever
  * the model's height (README.md:4; device/HavacHls.cpp:220-319): this is what keeps short models near that.
- * havac_ssv_last_kernel_variant: what the last enqueued pass ran (0 standard, 1 short). */
+ * havac_ssv_last_kernel_variant: what the last enqueued pass ran (0 standard, 1 resident tables). */
 int havac_ssv_set_kernel_variant(havac_ssv_ctx *ctx, int variant);
 int havac_ssv_last_kernel_variant(havac_ssv_ctx *ctx, int *variant);
 
