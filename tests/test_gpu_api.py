@@ -587,10 +587,13 @@ def test_bench_line_contract():
     assert d["cpu_baseline"]["vectorised_port"]["whole_hit_list_matches_gpu"] is True
 
 
-def test_bench_starts_its_own_ranks():
-    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself.  On
-    a one-GPU box both ranks share the card, so the records travel over gloo instead of RCCL (HAVAC_BENCH_BACKEND);
-    the launcher, the sharding, the variable-length gather and the per-rank report are the ones an 8-GPU run uses."""
+@pytest.mark.parametrize("world,rows,segments", [(2, 256, 400), (4, 1024, 150)])
+def test_bench_starts_its_own_ranks(world, rows, segments):
+    """`python bench.py --gpus N` with no launcher around it starts N ranks itself.  On
+    a one-GPU box all ranks share the card, so the records travel over gloo instead of RCCL (HAVAC_BENCH_BACKEND);
+    the launcher, the sharding, the variable-length gather and the per-rank report are the ones an 8-GPU run uses.
+    Two ranks with a 256-row model (the resident-table kernel on every shard) and four with a 1024-row one (the standard
+    kernel, a 1023-column halo on three of them, two boundary stretches checked against the CPU)."""
     import json
     import os
     import subprocess
@@ -598,23 +601,24 @@ def test_bench_starts_its_own_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HAVAC_BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--rows", "256", "--columns-per-gpu", str(400 * synth.SEGMENT)],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+                        "--rows", str(rows), "--columns-per-gpu", str(segments * synth.SEGMENT)],
                        capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["columns"] == 2 * 400 * synth.SEGMENT
+    assert d["n_gpus"] == world and d["config"]["columns"] == world * segments * synth.SEGMENT
     dd = d["distributed"]
-    assert dd["world"] == 2 and dd["backend"] == "gloo" and len(dd["per_rank"]) == 2
-    assert [p["rank"] for p in dd["per_rank"]] == [0, 1]
-    assert dd["per_rank"][0]["halo_cells"] == 0 and dd["per_rank"][1]["halo_cells"] == 255 * 256 // 2
+    assert dd["world"] == world and dd["backend"] == "gloo" and len(dd["per_rank"]) == world
+    assert [p["rank"] for p in dd["per_rank"]] == list(range(world))
+    assert dd["per_rank"][0]["halo_cells"] == 0 and all(p["halo_cells"] == (rows - 1) * rows // 2 for p in dd["per_rank"][1:])
+    assert d["kernel"]["name"] == ("ssv_resident_kernel" if rows <= 256 else "ssv_diag_kernel")
     assert sum(p["records"] for p in dd["per_rank"]) == d["config"]["hits_per_step"]
     assert all(p["kernel_ms"] > 0 for p in dd["per_rank"])
     # rank 0 has checked the gathered list before printing: order, counts, columns per rank, the records around the cut
     parity = dd["parity"]
     assert parity["ok"] and parity["counts_add_up"] and parity["device_order_no_duplicates"] and parity["ranks_inside_their_columns"]
-    assert len(parity["boundary_stretches"]) == 1 and parity["boundary_stretches"][0]["boundary_column"] == 400 * synth.SEGMENT
-    assert parity["boundary_stretches"][0]["equals_cpu_checker"] and parity["boundary_stretches"][0]["records"] > 0
+    assert len(parity["boundary_stretches"]) == min(2, world - 1) and parity["boundary_stretches"][0]["boundary_column"] == segments * synth.SEGMENT
+    assert all(b["equals_cpu_checker"] and b["records"] > 0 for b in parity["boundary_stretches"])
     assert d["clock_warmup_passes"] >= 3
