@@ -511,11 +511,15 @@ __device__ __forceinline__ LaneWords read_lane_words(uint32_t lds_address) {
 // the 8 bytes loaded for this chunk and are expanded entry by entry: window Q (steps 4Q..4Q+3) uses entries 2Q..2Q+16
 // only, so 17 of the 32 addresses (plus the four prepared words) are alive at a time -- the registers that let both
 // score sets stay alive at six waves per SIMD.
+constexpr uint32_t kFlagSafe = 1u, kFlagSpecial = 2u;
 struct LazySymbols {
     uint32_t even[2], odd[2];   // per packed word (pairs 16..23, 24..31): code*8 of its even / odd pairs, one per byte
     uint32_t separators;        // bit K: pair 16+K is a separator pair (boundary mode); 0 otherwise
     uint32_t table_base;
-    uint32_t special;           // wave-uniform, 0 or 1 (a 32-bit SGPR, not a lane mask): some position of the wave lies outside [0, N), or a separator is present
+    uint32_t special;           // wave-uniform flag word (a 32-bit SGPR, not a lane mask).  kFlagSpecial: some position of the wave lies outside [0, N), or a
+                                // separator is present; kFlagSafe (set by the chunk loop for the chunk it enters): the chunk may test for hits every four
+                                // steps.  ONE word for both: every window entry's asm takes it as an "s" operand, and with two such words alive through
+                                // the windows hipcc's allocator once moved one into a VGPR ("illegal VGPR to SGPR copy")
     int32_t valid_lo, valid_hi; // wave-uniform: positions relative to the wave's first that lie inside [0, N): [valid_lo, valid_hi)
 };
 
@@ -539,7 +543,7 @@ template <int K>
 __device__ __forceinline__ void expand_entry(uint32_t (&C)[32], const LazySymbols& z) {
     constexpr int n = K & 7;
     uint32_t entry = or_byte<n / 2>(z.table_base, (n & 1) ? z.odd[K / 8] : z.even[K / 8]);
-    if (fresh_uniform(z.special)) {
+    if (fresh_uniform(z.special) & kFlagSpecial) {
         // positions outside [0, N) and separator pairs use the 17th entry of the tables
         const uint32_t lane32 = fresh_lane() * 32u;           // computed here, in the rare chunks that need it (nothing that
                                                                 // depends on the lane number is kept in a VGPR through the windows)
@@ -820,7 +824,7 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
                 trace_step<true>(win, h * H + i, step0 + 4 * Q + 1, wave_diag0, mid[i], m[i].y, nxt[h * H + i], C[2 * Q + h * H + i], table_base);
         }
     }
-    if (!fresh_uniform(safe)) {
+    if (!(fresh_uniform(safe) & kFlagSafe)) {
         uint32_t any = 0;
 #pragma unroll
         for (int i = 0; i < kRegs; i++) any |= nxt[i];
@@ -861,7 +865,7 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
 #pragma unroll
     for (int i = 0; i < kRegs; i++) any |= nxt[i];
     if (const unsigned long long lanes = __ballot((any & kCrossedBits) != 0); __builtin_expect(lanes != 0, 0))
-        window_slow<Resident, Q, kWindowSteps>(cur, nxt, C, lanes, (int)(2u - 2u * safe), sink, staged, step0, wave_diag0, regs);
+        window_slow<Resident, Q, kWindowSteps>(cur, nxt, C, lanes, (int)(2u - 2u * (safe & kFlagSafe)), sink, staged, step0, wave_diag0, regs);
 }
 
 // ONE step with the tables of step pair 0 (the step behind the model's last chunk: the high cells run one row behind
@@ -1121,7 +1125,7 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             z.separators = separators;
             uint32_t special = e.edge;                                    // from scalars and a ballot only: stays on the scalar unit
             if (fresh_uniform(has_mask)) special |= __any(z.separators != 0) ? 1u : 0u;
-            z.special = opaque_uniform(special);
+            z.special = opaque_uniform(special ? kFlagSpecial : 0u);
             prepare_symbols(z, w.x, w.y);
         };
         auto fetch_symbols = [&](int64_t rel, LazySymbols& z, const uint32_t lane8) {
@@ -1180,8 +1184,8 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             // slide the window by 32 symbols
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-            const uint32_t safe = opaque_uniform((safe_now >> ((p0 >> 5) & 31u)) & 1u);
-            step_windows<Trace, false>(x, x2, C, z, safe, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
+            z.special = opaque_uniform(((safe_now >> ((p0 >> 5) & 31u)) & 1u) | (z.special & kFlagSpecial));     // + kFlagSafe for this chunk
+            step_windows<Trace, false>(x, x2, C, z, z.special, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
             asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the windows
             mine = read_lane_words(lane_words_address);
             next_rows = fetch_rows(p0 + kChunkRows, mine);        // rows[] has kModelSlack words behind the model
@@ -1365,7 +1369,7 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
         z.valid_lo = e.valid_lo; z.valid_hi = e.valid_hi;
         z.table_base = table_base;
         z.separators = 0;
-        z.special = opaque_uniform(e.edge);
+        z.special = opaque_uniform(e.edge ? kFlagSpecial : 0u);
         prepare_symbols(z, w.x, w.y);
     };
     // a tile's first diagonal and the first of its rows that can lie inside the matrix (ssv_diag_body: d0, p_lo)
@@ -1425,8 +1429,8 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
         for (uint32_t p0 = p_lo; p0 < p_hi; p0 += kChunkRows) {
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-            const uint32_t safe = opaque_uniform((safe_word >> (p0 >> 5)) & 1u);
-            step_windows<false, true>(x, x2, C, z, safe, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
+            z.special = opaque_uniform(((safe_word >> (p0 >> 5)) & 1u) | (z.special & kFlagSpecial));            // + kFlagSafe for this chunk
+            step_windows<false, true>(x, x2, C, z, z.special, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
             asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the windows
             if (p0 + kChunkRows < p_hi) {
                 // the next chunk's upper half (issued at the end of a chunk, consumed at the top of the next: see ssv_diag_body)
