@@ -53,11 +53,24 @@ def chunk_mix(path=DEFAULT, kernel="_ZN5havac15ssv_diag_kernel", verbose=False):
 
     memo = {}
 
-    def best(i):
-        """-> (vector instructions, list of instruction indices) of the cheapest way from line i to the back edge"""
+    def flow_exit(t):
+        """An if / else as the structurizer leaves it: `s_cbranch .. FLOW` over the `then` side, and in the block FLOW (named
+        %Flow..) a second conditional branch over the `else` side -- exactly one of the two sides runs.  -> the line of that second
+        branch if line t is such a Flow block, else None."""
+        if "%Flow" not in body[t]:
+            return None
+        for k in range(t + 1, min(t + 4, len(body))):
+            ins = instruction(k)
+            if ins and ins.startswith("s_cbranch") and label_at.get(ins.split()[-1], 0) > k:
+                return k
+        return None
+
+    def best(i, skip_at=None, take_at=None):
+        """-> (vector instructions, list of instruction indices) of the cheapest way from line i to the back edge; the conditional
+        branch at line `take_at` is taken, the one at `skip_at` is not (the two halves of a structurized if / else)"""
         path_here = []
         while True:
-            if i in memo:
+            if i in memo and skip_at is None and take_at is None:
                 n, rest = memo[i]
                 return n + sum(1 for k in path_here if instruction(k).startswith("v_")), path_here + rest
             if i > loop_end:                                             # left the loop: not a way round it
@@ -77,14 +90,27 @@ def chunk_mix(path=DEFAULT, kernel="_ZN5havac15ssv_diag_kernel", verbose=False):
                 if target is not None and op == "s_branch":
                     i = target
                     continue
+                if target is not None and i == take_at:
+                    i = target
+                    take_at = None
+                    continue
+                if i == skip_at:
+                    skip_at = None
+                    i += 1
+                    continue
                 if target is not None and 0 < target - i < NEAR:          # both ways
-                    a = best(i + 1)
-                    b = best(target)
-                    memo_key = path_here[0]
+                    second = flow_exit(target)
+                    if second is not None:                              # an if / else: the `then` side and not the `else` side, or the other way round
+                        a = best(i + 1, take_at=second)
+                        b = best(target, skip_at=second)
+                    else:
+                        a = best(i + 1)
+                        b = best(target)
                     n, rest = a if a[0] <= b[0] else b
                     mine = sum(1 for k in path_here if instruction(k).startswith("v_"))
-                    memo[memo_key] = (n + mine, path_here + rest)
-                    return memo[memo_key]
+                    if skip_at is None and take_at is None:
+                        memo[path_here[0]] = (n + mine, path_here + rest)
+                    return n + mine, path_here + rest
             i += 1
         mine = sum(1 for k in path_here if instruction(k).startswith("v_"))
         return mine, path_here
