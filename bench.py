@@ -11,12 +11,15 @@ A step is one whole pass of the hot path over one batch of synthetic input that
 is already resident in HBM: model padding copy + SSV kernel + hit compaction +
 ordering of the hit records into the reference's device order (+ for N > 1 the
 RCCL gather of the records to rank 0, where the rank lists concatenate to the
-ordered whole).  For passes of up to 1e12 cells three passes are in flight (--pipeline-depth), each with its own
+ordered whole).  Three passes are in flight for passes of up to 1e12 cells, two above (--pipeline-depth), each with its own
 context and hit buffer: while the host waits for the hit count of pass k, orders its records and gathers
-them (on the pass's own low-priority stream), the SSV kernel of pass k+1 runs; the SSV kernels of all
-passes are enqueued on one high-priority stream, back to back, never side by side, so their event-timed
-durations stay clean.  All K passes are complete when the timed region ends;
-`config.ms_per_step_strictly_serial` shows the same K passes with one in flight.
+them (on the pass's own low-priority stream), the SSV kernel of pass k+1 runs; the SSV kernels of consecutive
+passes alternate between two high-priority streams, so that a kernel starts while its predecessor drains (a launch's
+last, half-empty round of tiles and the gap between two dependent launches are filled by its neighbour: a step then
+takes LESS than one kernel alone).  All K passes are complete when the timed region ends.  `kernel.avg_ms` and
+`roofline` are the kernel ALONE: HIP events around the launch in the same K passes run strictly one after the other
+(`config.ms_per_step_strictly_serial`), where nothing shares the chip with it; `kernel.avg_ms_overlapped` is what the
+same events read inside the timed region.
 
 Workloads (BASELINE.json configs):
   c2 (default)  one pHMM of L = 1024 rows x 100 Mbp (100,012,032 columns after padding to 12288) per GPU; N > 1 is
@@ -422,10 +425,9 @@ def main():
     ap.add_argument("--columns-per-gpu", type=int, default=0, help="probe: this many columns (a multiple of 12288) per unit")
     ap.add_argument("--pipeline-depth", type=int, default=0,
                     help="passes in flight (own context, hit buffer and stream each): the ordering / gather of pass k "
-                         "overlaps the SSV kernel of pass k+1; the SSV kernels stay back to back.  1 = strictly serial; "
-                         "0 = 3 for passes up to 1e12 cells per GPU (C2 is 1e11), else 1: ordering tens of millions of "
-                         "records next to the following kernel slows that kernel by more than it hides "
-                         "(C3 shape: 303 vs 267 ms per step)")
+                         "overlaps the SSV kernel of pass k+1, which (passes of 2e10 cells and more) starts on a second kernel "
+                         "stream while kernel k drains.  1 = strictly serial; 0 = 3 for passes up to 1e12 cells per GPU "
+                         "(C2 is 1e11), 2 above (C3, C5; N > 1: the gather hides behind the next kernel), 1 above 1e14 cells on one GPU")
     ap.add_argument("--tuning", default="", help="experiments: rows_per_block,tiles_per_item,block_tails,ordering[,parts_log2,"
                     "split_rounds_x4,short_rows,guide] for havac_ssv_set_tuning / havac_ssv_set_split_tuning (-1 = the library's own "
                     "rule), e.g. --tuning=-1,-1,-1,0 orders with the radix sort")
@@ -494,11 +496,16 @@ def main():
     total_cells = ncols * nrows
     # records per cell: 1.0e-5 on C2, 0.9e-5 on the collection
     hit_capacity = max(1 << 20, int(my_cells * (4e-5 if my_cells <= 1e13 else 1.2e-5)))
-    # passes in flight: 3 for short passes; for long ones 2 when there is a gather to hide behind the next kernel (N > 1:
-    # C4 moves 36 GB to rank 0 per pass), else 1
-    depth = args.pipeline_depth if args.pipeline_depth > 0 else (3 if my_cells <= 1e12 else (2 if world > 1 else 1))
+    # passes in flight: 3 for short passes, 2 for long ones -- the next pass's kernel starts (on the second kernel stream) while
+    # this one drains, and for N > 1 the gather (C4: 36 GB to rank 0 per pass) hides behind it; 1 above 1e14 cells on one GPU
+    # (C4 on one card: 93 GB of hit and ordering buffers per pass in flight)
+    depth = args.pipeline_depth if args.pipeline_depth > 0 else (3 if my_cells <= 1e12 else (2 if world > 1 or my_cells <= 1e14 else 1))
+    # kernels of consecutive passes side by side (two kernel streams) where a pass is long enough to gain from it
+    kernel_streams = 2 if my_cells >= 2e10 else 1
+    if os.environ.get("HAVAC_KERNEL_STREAMS"):
+        kernel_streams = int(os.environ["HAVAC_KERNEL_STREAMS"])
     tuning = [int(v) for v in args.tuning.split(",")] if args.tuning else None
-    engine = ShardedSsv(hit_capacity, device, depth=depth, gather_when_alone=use_dist, tuning=tuning)
+    engine = ShardedSsv(hit_capacity, device, depth=depth, gather_when_alone=use_dist, tuning=tuning, kernel_streams=kernel_streams)
     if world > 1:
         engine.set_sequence_window(win_first, win_end - win_first)
     wave_slots = engine.ctx.wave_slots()
@@ -556,6 +563,7 @@ def main():
     # engine is given back before anything else is allocated.  Rank 0 of `--gpus 8 --workload c4` holds 36 GB of records per receive buffer (DESIGN.md section 6
     # has the sum); the checks below allocate nothing of that size.
     engine_variant = engine.ctx.last_kernel_variant()
+    kernel_streams = 2 if getattr(engine, "kernel_stream2", None) is not None else 1      # (what the engine really used)
     engine.release()
     if depth > 1:       # the same steps strictly one after the other, for the record (not `value`)
         serial = ShardedSsv(hit_capacity, device, depth=1, gather_when_alone=use_dist, tuning=tuning)
@@ -579,7 +587,7 @@ def main():
         h = min(nrows - 1, lo)
         halo = h * (h + 1) // 2 + (nrows - 1 - h) * lo     # cells left of its columns a rank recomputes: sum over rows p of min(p, lo)
         mine = {"rank": rank, "device": torch.cuda.get_device_name(device), "columns": [lo, hi], "records": int(found),
-                "kernel_ms": round(float(np.mean([k[0] for k in kernel_ms])), 4), "halo_cells": int(halo),
+                "kernel_ms": round(float(np.mean([k[0] for k in serial_timings])), 4), "halo_cells": int(halo),
                 "gather_ms": round(float(np.mean(gather_ms)), 4) if gather_ms else None}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
@@ -587,7 +595,10 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         gcups = total_cells / (elapsed / args.steps) / 1e9
-        ssv_ms = float(np.mean([k[0] for k in kernel_ms]))
+        # the kernel alone: the strictly serial passes' event times (with passes in flight a kernel shares the chip with the
+        # head of its successor and the tail of its predecessor, and its events show that)
+        ssv_ms = float(np.mean([k[0] for k in serial_timings]))
+        ssv_ms_overlapped = float(np.mean([k[0] for k in kernel_ms]))
         enq_ms = float(np.mean([k[1] for k in serial_timings]))   # of the strictly serial passes: no queueing in it
         nhits = int(merged.numel())
         # algorithmic HBM bytes of this rank's launch: its share of the packed sequence once, the
@@ -609,7 +620,7 @@ def main():
                              (f" [--columns-per-gpu {args.columns_per_gpu}]" if args.columns_per_gpu else "") +
                              "; int8 SSV, one kernel launch per step and GPU"),
                 "rows": nrows, "columns": ncols, "columns_per_gpu": cols_per_gpu, "cells_per_step": total_cells,
-                "hits_per_step": nhits, "planted_homologs": planted, "passes_in_flight": depth,
+                "hits_per_step": nhits, "planted_homologs": planted, "passes_in_flight": depth, "kernel_streams": kernel_streams,
                 "ms_per_step_strictly_serial": None if serial_ms is None else round(serial_ms, 4),
                 "value_strictly_serial": None if serial_ms is None else round(total_cells / serial_ms / 1e6, 2),
                 "parallelism": f"column-sharded x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} gather of hit records to rank 0" if use_dist else ""),
@@ -617,11 +628,17 @@ def main():
                 "work_distribution": describe_plan(ncols, nrows, rank, world, tuning, wave_slots),
             },
             "kernel": {"name": "ssv_resident_kernel" if engine_variant else "ssv_diag_kernel", "avg_ms": round(ssv_ms, 4), "enqueue_to_ordered_ms": round(enq_ms, 4),
-                       "gcups_kernel_only": round(my_cells / kernel_s / 1e9, 1)},
+                       "gcups_kernel_only": round(my_cells / kernel_s / 1e9, 1),
+                       "avg_ms_source": "HIP events on the launch stream, " + ("the K strictly serial passes (kernel alone)" if depth > 1 else "the timed passes (one in flight: kernel alone)"),
+                       "avg_ms_overlapped": round(ssv_ms_overlapped, 4) if depth > 1 else None,
+                       "kernel_streams": kernel_streams},
             "roofline": {
                 "bound": "valu", "achieved": round(achieved_tiops, 2), "peak": PEAK_TIOPS_I16,
                 "unit": "Tiop/s (int16 saturating adds, 1 per cell; the score select is served by LDS)",
                 "frac": round(achieved_tiops / PEAK_TIOPS_I16, 4),
+                # what the chip sustained over the timed region (launches overlapping): this rank's cells x K / wall time
+                "sustained": {"achieved": round(my_cells * OPS_PER_CELL / (elapsed / args.steps) / 1e12, 2),
+                              "frac": round(my_cells * OPS_PER_CELL / (elapsed / args.steps) / 1e12 / PEAK_TIOPS_I16, 4)},
                 "frac_vs_full_rate_class_peak": round(achieved_tiops / PEAK_TIOPS_I16_FULL_RATE_CLASS, 4),
                 # SURVEY.md 8d wrote the VALU fraction as GCUPS*1e9*2/3.93e13 (select AND add on the VALU, 32-bit lanes);
                 # it exceeds 1 here because the select is served by LDS

@@ -232,14 +232,16 @@ class ShardedSsv:
     depth > 1 keeps that many passes in flight, each with its own context, hit buffer and ordering stream:
     ``submit`` enqueues a pass, ``collect`` finishes the oldest one.  While the host waits for pass k's hit count,
     orders its records and (N > 1) gathers them over RCCL, the SSV kernel of pass k+1 is already running.  The SSV
-    kernels of all passes are enqueued on ONE high-priority stream: back to back, never side by side, and never
-    behind another pass's ordering (havac_ssv_set_order_stream puts that on the slot's own low-priority stream), so a
-    kernel's event-timed duration stays the duration of that kernel alone.
+    kernels of consecutive passes alternate between two high-priority streams -- a kernel starts as its predecessor
+    drains -- and never wait behind another pass's ordering (havac_ssv_set_order_stream puts that on the slot's own
+    low-priority stream).  A kernel's event-timed duration includes what its neighbours took of the chip meanwhile; a
+    depth-1 engine measures a kernel alone.
 
     The records ``collect`` returns live in the slot's receive buffer (world > 1) or hit buffer (world == 1): they
     are valid until that slot is submitted again, and the caller's current stream has been made to wait for them."""
 
-    def __init__(self, hit_capacity: int, device: torch.device, depth: int = 1, gather_when_alone: bool = False, tuning=None):
+    def __init__(self, hit_capacity: int, device: torch.device, depth: int = 1, gather_when_alone: bool = False, tuning=None,
+                 kernel_streams: int | None = None):
         """tuning: optional (rows_per_block, tiles_per_item, block_tails, ordering[, parts_log2, split_rounds_x4, short_rows, guide])
         for SsvContext.set_tuning / set_split_tuning (experiments)"""
         self.device = device
@@ -257,6 +259,18 @@ class ShardedSsv:
                     slot.ctx.set_kernel_variant(tuning[8])
         _low, high = torch.cuda.Stream.priority_range()
         self.kernel_stream = torch.cuda.Stream(device, priority=high) if depth > 1 else None
+        # Consecutive passes' kernels alternate between TWO high-priority streams (round 4): a kernel then starts while its
+        # predecessor drains -- the last, half-empty round of a launch's tiles and the ~25 us between two dependent launches
+        # are filled by its neighbour's first workgroups -- instead of behind its end: C2 1.878 -> 1.834 ms per step, less than
+        # one kernel takes alone (1.850).  A kernel's event-timed duration then includes its neighbour's share of the chip;
+        # the duration of a kernel ALONE is what a depth-1 engine measures (bench.py does, for `roofline`).
+        # kernel_streams = 1 (or HAVAC_KERNEL_STREAMS=1): one stream, kernels back to back, never side by side (rounds 2-3) --
+        # what passes of a fraction of a millisecond want: two 0.13 ms kernels side by side, each with its preparation and
+        # its tails behind it, get in each other's way (a 64-row model x 100 Mbp: 0.221 against 0.200 ms per step).
+        if kernel_streams is None:
+            kernel_streams = int(os.environ.get("HAVAC_KERNEL_STREAMS", "2"))
+        self.kernel_stream2 = torch.cuda.Stream(device, priority=high) if depth > 1 and kernel_streams > 1 else None
+        self._flip = 0
         self.in_flight = []               # slot indices, oldest first
         self.next_slot = 0
         self.ctx = self.slots[0].ctx      # the context of the most recently collected pass (for last_ms)
@@ -275,6 +289,10 @@ class ShardedSsv:
             raise RuntimeError("every slot is in flight: collect() first")
         slot = self.slots[self.next_slot]
         stream = self.kernel_stream if self.kernel_stream is not None else torch.cuda.current_stream(self.device)
+        if self.kernel_stream2 is not None:
+            self._flip ^= 1
+            if self._flip:
+                stream = self.kernel_stream2
         if self.kernel_stream is not None:
             stream.wait_stream(torch.cuda.current_stream(self.device))      # the caller's inputs
             if self.world > 1 or self.gather_when_alone:

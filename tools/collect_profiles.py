@@ -26,8 +26,19 @@ for w in ("c2", "c3", "c5"):
         out = os.path.join(P, f"{dst_tag}_kernel_stats_{w}.csv")
         with open(out, "w") as f:
             f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {w} --no-pmc --no-cpu-baseline (MI355X; {note}); "
-                    "every launch of the run is in the average, warm-up included; kernel names shortened\n")
+                    "every launch of the run is in the average, warm-up and the strictly serial passes included; with passes in flight consecutive SSV kernels "
+                    "overlap (two kernel streams) and their durations include the neighbour's share of the chip; kernel names shortened\n")
             for r in rows:
+                r[0] = r[0].split("(")[0]
+                f.write(",".join(r) + "\n")
+        print("profiles/" + os.path.basename(out))
+    stats = os.path.join(G, f"{src_tag}_prof_{w}_serial", f"{w}_kernel_stats.csv")
+    if os.path.isfile(stats):
+        out = os.path.join(P, f"{dst_tag}_kernel_stats_{w}_one_pass_in_flight.csv")
+        with open(out, "w") as f:
+            f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {w} --pipeline-depth 1 --no-pmc --no-cpu-baseline (MI355X; {note}); "
+                    "one pass in flight: every SSV kernel runs alone (the duration `roofline` is computed from); warm-up included; kernel names shortened\n")
+            for r in csv.reader(open(stats)):
                 r[0] = r[0].split("(")[0]
                 f.write(",".join(r) + "\n")
         print("profiles/" + os.path.basename(out))

@@ -9,6 +9,9 @@ for w in c2 c3 c5; do
     python3 bench.py --workload $w > gpurun_out/${tag}_bench_$w.json 2> gpurun_out/${tag}_bench_$w.err || echo "bench $w failed"
     tail -c 400 gpurun_out/${tag}_bench_$w.json; echo
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_$w -o $w -- python3 bench.py --workload $w --no-pmc --no-cpu-baseline > gpurun_out/${tag}_bench_${w}_under_rocprof.json 2> gpurun_out/${tag}_prof_$w.err || echo "rocprof $w failed"
+    # the kernel ALONE (what `roofline` is computed from): the same command with one pass in flight -- with several, consecutive kernels
+    # share the chip (two kernel streams) and the trace's durations include the neighbour's share
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_${w}_serial -o $w -- python3 bench.py --workload $w --pipeline-depth 1 --no-pmc --no-cpu-baseline > gpurun_out/${tag}_bench_${w}_serial_under_rocprof.json 2> gpurun_out/${tag}_prof_${w}_serial.err || echo "rocprof $w serial failed"
     bash tools/pmc_passes.sh $w dfam ${tag}_$w > /dev/null 2>&1 || echo "pmc $w failed"
     cat gpurun_out/pmc_${tag}_${w}_summary.csv | head -40
 done
