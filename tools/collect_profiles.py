@@ -28,6 +28,19 @@ for w in ("c2", "c3", "c5"):
             f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {w} --no-pmc --no-cpu-baseline (MI355X; {note}); "
                     "every launch of the run is in the average, warm-up and the strictly serial passes included; with passes in flight consecutive SSV kernels "
                     "overlap (two kernel streams) and their durations include the neighbour's share of the chip; kernel names shortened\n")
+            trace = os.path.join(G, f"{src_tag}_prof_{w}", f"{w}_kernel_trace.csv")
+            if os.path.isfile(trace):      # the same trace, launches that ran alone apart from those that overlapped a neighbour
+                ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(trace))
+                            if "ssv_diag_kernel" in r["Kernel_Name"] or "ssv_resident_kernel" in r["Kernel_Name"])
+                d = [(b - a) / 1e6 for a, b in ks]
+                late = [i > 0 and ks[i][0] < ks[i - 1][1] for i in range(len(ks))]          # started while its predecessor ran
+                early = [i + 1 < len(ks) and ks[i + 1][0] < ks[i][1] for i in range(len(ks))]  # its successor started before it ended
+                alone = [d[i] for i in range(1, len(ks)) if not late[i] and not early[i]]
+                over = [d[i] for i in range(len(ks)) if late[i]]
+                if alone:
+                    f.write(f"# SSV kernel, from the kernel trace of this run: {len(alone)} launches that shared the chip with no other SSV kernel (the strictly "
+                            f"serial passes, warm-up): mean {sum(alone) / len(alone):.4f} ms, min {min(alone):.4f} ms -- the duration `kernel.avg_ms` / `roofline` state; "
+                            + (f"{len(over)} launches that started while their predecessor ran (the pipelined passes): mean {sum(over) / len(over):.4f} ms\n" if over else "none overlapped\n"))
             for r in rows:
                 r[0] = r[0].split("(")[0]
                 f.write(",".join(r) + "\n")
