@@ -11,10 +11,10 @@ A step is one whole pass of the hot path over one batch of synthetic input that
 is already resident in HBM: model padding copy + SSV kernel + hit compaction +
 ordering of the hit records into the reference's device order (+ for N > 1 the
 RCCL gather of the records to rank 0, where the rank lists concatenate to the
-ordered whole).  Two passes are in flight (three for passes below 2e10 cells; --pipeline-depth), each with its own
+ordered whole).  Two passes are in flight (--pipeline-depth), each with its own
 context and hit buffer: while the host waits for the hit count of pass k, orders its records and gathers
 them (on the pass's own low-priority stream), the SSV kernel of pass k+1 runs; the SSV kernels of consecutive
-passes alternate between two high-priority streams, so that a kernel starts while its predecessor drains (a launch's
+passes (of 4e10 cells and more) alternate between two high-priority streams, so that a kernel starts while its predecessor drains (a launch's
 last, half-empty round of tiles and the gap between two dependent launches are filled by its neighbour: a step then
 takes LESS than one kernel alone).  All K passes are complete when the timed region ends.  `kernel.avg_ms` and
 `roofline` are the kernel ALONE: HIP events around the launch in the same K passes run strictly one after the other
@@ -425,9 +425,9 @@ def main():
     ap.add_argument("--columns-per-gpu", type=int, default=0, help="probe: this many columns (a multiple of 12288) per unit")
     ap.add_argument("--pipeline-depth", type=int, default=0,
                     help="passes in flight (own context, hit buffer and stream each): the ordering / gather of pass k "
-                         "overlaps the SSV kernel of pass k+1, which (passes of 2e10 cells and more) starts on a second kernel "
-                         "stream while kernel k drains.  1 = strictly serial; 0 = 2 (C2, C3, C5; N > 1: the gather hides behind the next "
-                         "kernel), 3 for passes below 2e10 cells (one kernel stream), 1 above 1e14 cells on one GPU")
+                         "overlaps the SSV kernel of pass k+1, which (passes of 4e10 cells and more) starts on a second kernel "
+                         "stream while kernel k drains.  1 = strictly serial; 0 = 2 (N > 1: the gather hides behind the next "
+                         "kernel), 1 above 1e14 cells on one GPU")
     ap.add_argument("--tuning", default="", help="experiments: rows_per_block,tiles_per_item,block_tails,ordering[,parts_log2,"
                     "split_rounds_x4,short_rows,guide] for havac_ssv_set_tuning / havac_ssv_set_split_tuning (-1 = the library's own "
                     "rule), e.g. --tuning=-1,-1,-1,0 orders with the radix sort")
@@ -496,19 +496,19 @@ def main():
     total_cells = ncols * nrows
     # records per cell: 1.0e-5 on C2, 0.9e-5 on the collection
     hit_capacity = max(1 << 20, int(my_cells * (4e-5 if my_cells <= 1e13 else 1.2e-5)))
-    # kernels of consecutive passes side by side (two kernel streams) where a pass is long enough to gain from it
-    kernel_streams = 2 if my_cells >= 2e10 else 1
+    # kernels of consecutive passes side by side (two kernel streams) where a pass is long enough to gain from it (512 rows x
+    # 100 Mbp, 5.1e10 cells: +1.8 %; 1024 rows: +3.5 %; 256 rows, 2.6e10 cells, the resident-table kernel: -4 %)
+    kernel_streams = 2 if my_cells >= 4e10 else 1
     if os.environ.get("HAVAC_KERNEL_STREAMS"):
         kernel_streams = int(os.environ["HAVAC_KERNEL_STREAMS"])
     # passes in flight: 2 where kernels overlap -- the next pass's kernel starts (on the second kernel stream) while this one
     # drains, the host's wait, the ordering and for N > 1 the gather (C4: 36 GB to rank 0 per pass) hide behind it; a third
     # pass in flight only adds a third kernel's preparation and ordering to the mix (C2: 1.819-1.821 ms per step with two,
-    # 1.831-1.844 with three, 1.889 with four, one box) -- 3 for the short passes that keep one kernel stream; 1 above 1e14 cells
-    # on one GPU (C4 on one card: 93 GB of hit and ordering buffers per pass in flight)
+    # 1.831-1.844 with three, 1.889 with four, one box; short passes on one kernel stream likewise: 64 rows x 100 Mbp 0.175 ms
+    # per step with two, 0.200 with three; 256 rows 0.507 against 0.530); 1 above 1e14 cells on one GPU (C4 on one card: 93 GB
+    # of hit and ordering buffers per pass in flight)
     if args.pipeline_depth > 0:
         depth = args.pipeline_depth
-    elif kernel_streams == 1:
-        depth = 3 if my_cells <= 1e12 else (2 if world > 1 else 1)
     else:
         depth = 2 if world > 1 or my_cells <= 1e14 else 1
     tuning = [int(v) for v in args.tuning.split(",")] if args.tuning else None
