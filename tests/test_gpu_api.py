@@ -600,6 +600,8 @@ def test_bench_starts_its_own_ranks(world, rows, segments):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HAVAC_BENCH_BACKEND="gloo")
+    if world == 4:
+        env["HAVAC_KERNEL_STREAMS"] = "2"      # consecutive passes' kernels side by side, as a full-size run has them (these shards are too small to choose it)
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
                         "--rows", str(rows), "--columns-per-gpu", str(segments * synth.SEGMENT)],
@@ -614,6 +616,7 @@ def test_bench_starts_its_own_ranks(world, rows, segments):
     assert [p["rank"] for p in dd["per_rank"]] == list(range(world))
     assert dd["per_rank"][0]["halo_cells"] == 0 and all(p["halo_cells"] == (rows - 1) * rows // 2 for p in dd["per_rank"][1:])
     assert d["kernel"]["name"] == ("ssv_resident_kernel" if rows <= 256 else "ssv_diag_kernel")
+    assert d["config"]["passes_in_flight"] == 2 and d["config"]["kernel_streams"] == (2 if world == 4 else 1)
     assert sum(p["records"] for p in dd["per_rank"]) == d["config"]["hits_per_step"]
     assert all(p["kernel_ms"] > 0 for p in dd["per_rank"])
     # rank 0 has checked the gathered list before printing: order, counts, columns per rank, the records around the cut
