@@ -405,6 +405,35 @@ def distributed_parity(hits: OrderedHits, counts, spans, packed, model, cores, s
     return out
 
 
+class Watchdog:
+    """N > 1: a rank that stays in one stage longer than the deadline says which rank and which stage on stderr and ends the
+    process with a non-zero code (os._exit: a fresh exit, nothing re-executed) -- under torch.distributed.run that ends the
+    job.  Without it a rank that died, or a collective a peer never reaches, leaves the other ranks waiting until the
+    driver's own limit.  The C-ABI gather has the same deadline on its own host waits (havac_gather_set_deadline)."""
+
+    def __init__(self, rank: int, limit_s: float):
+        import threading
+        self.rank, self.limit, self.name, self.since = rank, limit_s, "start", time.monotonic()
+        self.stage_limit = limit_s
+        self._stop = threading.Event()
+        if limit_s > 0:
+            threading.Thread(target=self._watch, daemon=True).start()
+
+    def stage(self, name: str, limit_s: float | None = None):
+        self.name, self.since, self.stage_limit = name, time.monotonic(), (self.limit if limit_s is None else limit_s)
+
+    def stop(self):
+        self._stop.set()
+
+    def _watch(self):
+        while not self._stop.wait(0.5):
+            waited = time.monotonic() - self.since
+            if self.limit > 0 and waited > self.stage_limit:
+                print(f"bench.py: rank {self.rank} has been in stage '{self.name}' for {waited:.0f} s (deadline {self.stage_limit:.0f} s): "
+                      "giving up, exit code 3", file=sys.stderr, flush=True)
+                os._exit(3)
+
+
 def launch_workers(args, argv):
     """python bench.py --gpus N without a launcher: start N ranks as a child process (nothing in this process has
     touched a GPU), pass their output through, exit with their code."""
@@ -431,6 +460,23 @@ def main():
     ap.add_argument("--tuning", default="", help="experiments: rows_per_block,tiles_per_item,block_tails,ordering[,parts_log2,"
                     "split_rounds_x4,short_rows,guide] for havac_ssv_set_tuning / havac_ssv_set_split_tuning (-1 = the library's own "
                     "rule), e.g. --tuning=-1,-1,-1,0 orders with the radix sort")
+    ap.add_argument("--kernel-streams", type=int, default=0, choices=(0, 1, 2),
+                    help="streams the SSV kernels of consecutive passes alternate between: 0 = the library's rule (two from 4e10 cells per "
+                         "shard on), 1 = back to back, 2 = side by side")
+    ap.add_argument("--backend", default=os.environ.get("HAVAC_BENCH_BACKEND", "nccl"), choices=("nccl", "gloo"),
+                    help="torch.distributed backend of an N > 1 run: nccl (= RCCL, one rank per GPU: what the driver runs) or gloo (a "
+                         "rehearsal with several ranks on ONE GPU, which RCCL refuses)")
+    ap.add_argument("--gather", default="c_abi", choices=("c_abi", "torch"),
+                    help="N > 1: the records travel through libhavac_dev.so's own RCCL calls (havac_gather_*) or through torch.distributed")
+    ap.add_argument("--gather-library", default="",
+                    help="rehearsals: a stand-in for librccl.so.1 (tests/native/rccl_standin.cpp) handed to havac_gather_use_library, so that "
+                         "the C-ABI gather runs between ranks that share a GPU; with --backend gloo")
+    ap.add_argument("--force-dist", action="store_true", default=os.environ.get("HAVAC_BENCH_FORCE_DIST") == "1",
+                    help="run the N > 1 code path (process group, gather, barrier) with the ranks there are, even one")
+    ap.add_argument("--deadline", type=float, default=180.0,
+                    help="N > 1: seconds a rank may spend in one stage (a pass with its gather, a barrier, a check) before it says which "
+                         "rank and stage and exits non-zero; also the deadline of every host wait of the C-ABI gather.  0 = none")
+    ap.add_argument("--die-at", default="", help=argparse.SUPPRESS)     # tests: "RANK:PASS[:hang]" -- before that pass of the timed region that rank leaves (os._exit), or stops making calls
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="N > 1: skip rank 0's check of the gathered list (distributed.parity)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
@@ -452,9 +498,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
-    # HAVAC_BENCH_FORCE_DIST=1: rehearse the N > 1 code path (process group, gather, barrier, all-reduce) with the
+    # --force-dist: rehearse the N > 1 code path (process group, gather, barrier, all-reduce) with the
     # ranks there are, even one -- the only way to run it over RCCL on a 1-GPU box
-    use_dist = world > 1 or os.environ.get("HAVAC_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or args.force_dist
+    die_at = tuple(int(v) if v.isdigit() else v for v in args.die_at.split(":")) if args.die_at else None
+    watchdog = Watchdog(rank, args.deadline if use_dist else 0.0)
 
     # HBM traffic from the counters, by a child under rocprofv3, BEFORE this process initialises the GPU
     traffic, traffic_note = None, "not measured (N > 1, --no-pmc, or a pass of more than 1e13 cells)"
@@ -470,9 +518,9 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # HAVAC_BENCH_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the N>1 path on a 1-GPU box
+    # --backend gloo lets several ranks share one GPU for a rehearsal of the N>1 path on a 1-GPU box
     # (RCCL refuses two ranks on one device); the driver's real multi-GPU runs use the default, nccl = RCCL.
-    backend = os.environ.get("HAVAC_BENCH_BACKEND", "nccl")
+    backend = args.backend
     ndev = torch.cuda.device_count()
     dev_index = local_rank if backend == "nccl" else local_rank % ndev
     torch.cuda.set_device(dev_index)
@@ -481,10 +529,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29500))
+        watchdog.stage("process group")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        from havac_amd import dist as hdist
+        hdist.set_gather_route(args.gather)
+        if args.gather_library:
+            hdist.use_gather_library(os.path.abspath(args.gather_library))
+        hdist.set_gather_deadline(args.deadline)
 
     from havac_amd.ssv import shard_window
     # a rank holds only the columns its shard reads (N > 1); the host copy stays whole for the checks behind the timed region
@@ -498,9 +552,8 @@ def main():
     hit_capacity = max(1 << 20, int(my_cells * (4e-5 if my_cells <= 1e13 else 1.2e-5)))
     # kernels of consecutive passes side by side (two kernel streams) where a pass is long enough to gain from it (512 rows x
     # 100 Mbp, 5.1e10 cells: +1.8 %; 1024 rows: +3.5 %; 256 rows, 2.6e10 cells, the resident-table kernel: -4 %)
-    kernel_streams = 2 if my_cells >= 4e10 else 1
-    if os.environ.get("HAVAC_KERNEL_STREAMS"):
-        kernel_streams = int(os.environ["HAVAC_KERNEL_STREAMS"])
+    # (the rule itself lives in ShardedSsv; --kernel-streams 1 / 2 force one or the other)
+    kernel_streams = args.kernel_streams or None
     # passes in flight: 2 where kernels overlap -- the next pass's kernel starts (on the second kernel stream) while this one
     # drains, the host's wait, the ordering and for N > 1 the gather (C4: 36 GB to rank 0 per pass) hide behind it; a third
     # pass in flight only adds a third kernel's preparation and ordering to the mix (C2: 1.819-1.821 ms per step with two,
@@ -517,15 +570,27 @@ def main():
         engine.set_sequence_window(win_first, win_end - win_first)
     wave_slots = engine.ctx.wave_slots()
 
-    def fence():
+    def fence(stage="fence"):
+        # What this rank has queued is complete BEFORE torch's collective starts: the gather's communicator (libhavac_dev.so's own)
+        # and torch's must never have operations in flight side by side (two communicators used concurrently can hang); the
+        # records still travelling behind the last pass are waited for with the gather's deadline, not inside a synchronize
+        # that a dead peer would never let return.
+        watchdog.stage(stage)
+        engine_now.wait_gathers()
+        torch.cuda.synchronize(device)
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize(device)
+            torch.cuda.synchronize(device)
 
-    def run_steps(engine, nsteps):
+    def run_steps(engine, nsteps, stage="passes"):
         """`nsteps` whole passes, all finished on return -> (last result, per-pass (kernel ms, enqueue-to-ordered ms))"""
         result, timings = None, []
-        for _ in range(nsteps):
+        for k in range(nsteps):
+            watchdog.stage(f"{stage}: pass {k + 1} of {nsteps}")
+            if die_at and die_at[:2] == (rank, k + 1) and stage == "timed region":      # (tests only)
+                if len(die_at) > 2:
+                    time.sleep(3600)         # a rank that hangs: its own watchdog, and every peer's, must end the job
+                os._exit(17)                 # a rank that dies without a word
             engine.submit(d_seq, ncols, d_phmm, nrows)
             if len(engine.in_flight) == len(engine.slots):
                 result = engine.collect()
@@ -537,31 +602,34 @@ def main():
 
     # set-up, not warm-up: one pass through every slot so that each context has its sort buffers before anything is
     # timed (a slot first used inside the timed region would pay a hipMalloc there when --warmup < --pipeline-depth)
-    run_steps(engine, depth)
+    engine_now = engine
+    run_steps(engine, depth, "set-up")
     # Clock warm-up, independent of --warmup: under this load the GPU reaches its clock only after ~10 launches of 2 ms (the
     # kernel's duration falls from 2.11 to 1.83 ms over the first ten launches of a run).  Untimed passes until the kernel's
     # event time has stopped falling -- three passes in a row within 0.5 % of the best seen -- at most 30 passes or 3 s.
     clock_passes, best_ms, steady, t_clock = 0, None, 0, time.perf_counter()
     while True:
-        _, t = run_steps(engine, 1)
+        _, t = run_steps(engine, 1, "clock warm-up")
         clock_passes += 1
         k_ms = t[-1][0]
         steady = steady + 1 if (best_ms is not None and k_ms <= best_ms * 1.005) else 0
         best_ms = k_ms if best_ms is None else min(best_ms, k_ms)
         done = steady >= 3 or clock_passes >= 30 or time.perf_counter() - t_clock > 3.0
         if use_dist:      # a pass holds a collective: every rank goes on until all are done
+            engine.wait_gathers()
+            torch.cuda.synchronize(device)      # (see fence: nothing of the gather's communicator in flight beside torch's)
             flag = torch.tensor([1 if done else 0], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             done = bool(flag.item())
         if done:
             break
-    run_steps(engine, args.warmup)
+    run_steps(engine, args.warmup, "warm-up")
     engine.gather_times()
     engine.gather_ms = []
-    fence()
+    fence("barrier in front of the timed region")
     t0 = time.perf_counter()
-    (merged, found), kernel_ms = run_steps(engine, args.steps)
-    fence()
+    (merged, found), kernel_ms = run_steps(engine, args.steps, "timed region")
+    fence("barrier behind the timed region")
     elapsed = time.perf_counter() - t0
     gather_ms = list(engine.gather_times())
     serial_ms, serial_timings = None, kernel_ms
@@ -570,22 +638,24 @@ def main():
     # engine is given back before anything else is allocated.  Rank 0 of `--gpus 8 --workload c4` holds 36 GB of records per receive buffer (DESIGN.md section 6
     # has the sum); the checks below allocate nothing of that size.
     engine_variant = engine.ctx.last_kernel_variant()
-    kernel_streams = 2 if getattr(engine, "kernel_stream2", None) is not None else 1      # (what the engine really used)
+    kernel_streams = 2 if engine.used_two_streams else 1      # (what the engine really used)
     engine.release()
     if depth > 1:       # the same steps strictly one after the other, for the record (not `value`)
         serial = ShardedSsv(hit_capacity, device, depth=1, gather_when_alone=use_dist, tuning=tuning)
+        engine_now = serial
         if world > 1:
             serial.set_sequence_window(win_first, win_end - win_first)
-        run_steps(serial, 2)
-        fence()
+        run_steps(serial, 2, "strictly serial passes, set-up")
+        fence("barrier in front of the strictly serial passes")
         t1 = time.perf_counter()
-        _, serial_timings = run_steps(serial, args.steps)
-        fence()
+        _, serial_timings = run_steps(serial, args.steps, "strictly serial passes")
+        fence("barrier behind the strictly serial passes")
         serial_ms = (time.perf_counter() - t1) / args.steps * 1e3
         serial.release()
         del serial
     torch.cuda.empty_cache()
     per_rank, failed = None, None
+    watchdog.stage("per-rank report (all-reduce, all-gather of objects)")
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -634,6 +704,9 @@ def main():
                             "inside the timed region, and each pass's hit list is checked as before"),
                 "ms_per_step_strictly_serial": None if serial_ms is None else round(serial_ms, 4),
                 "value_strictly_serial": None if serial_ms is None else round(total_cells / serial_ms / 1e6, 2),
+                # which figure a caller of the reference's one-run-at-a-time API sees (host/HavacHwClient.cpp:141-157): run, wait, list
+                "api_path": "strictly serial (value_strictly_serial): one run at a time, as the reference's HavacHwClient; `value` keeps "
+                            "passes in flight",
                 "parallelism": f"column-sharded x{world}" + (f", {'RCCL' if backend == 'nccl' else backend} gather of hit records to rank 0" if use_dist else ""),
                 "baseline": "1739 GCUPS = reference README.md:4, 1x Alveo U50 FPGA",
                 "work_distribution": describe_plan(ncols, nrows, rank, world, tuning, wave_slots),
@@ -668,13 +741,15 @@ def main():
                 "world": dist.get_world_size(), "backend": dist.get_backend(),
                 "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
                 "gather": ("all_gather of the counts + grouped send/recv of exactly count[r] records into one buffer on rank 0" +
-                           (", RCCL called by libhavac_dev.so (havac_gather_*)" if backend == "nccl" and os.environ.get("HAVAC_GATHER", "c_abi") != "torch"
-                            else ", through torch.distributed")),
+                           (", RCCL called by libhavac_dev.so (havac_gather_*)" + (f" [stand-in library {os.path.basename(args.gather_library)}]" if args.gather_library else "")
+                            if args.gather == "c_abi" and (backend == "nccl" or args.gather_library) else ", through torch.distributed")),
+                "deadline_s": args.deadline,
                 "gather_ms_rank0": round(float(np.mean(gather_ms)), 4) if gather_ms else None,
                 "per_rank": per_rank,
             }
         cores = min(16, len(os.sched_getaffinity(0)))   # a 1-GPU box's CPU share
         ordered = OrderedHits(merged, nrows)
+        watchdog.stage("checks of the list on rank 0 (CPU checker)", limit_s=max(args.deadline, 900.0))
         if use_dist and not args.no_parity_check:
             spans = [tuple(r["columns"]) for r in per_rank]
             out["distributed"]["parity"] = distributed_parity(ordered, [r["records"] for r in per_rank], spans, packed, model, cores)
@@ -691,10 +766,12 @@ def main():
                                        base["vectorised_port"].get("whole_hit_list_matches_gpu", base["vectorised_port"].get("stretch_matches_gpu"))):
             failed = "cpu_baseline: the CPU checker's records differ from the GPU's"
     if use_dist:
+        watchdog.stage("last barrier (rank 0 is checking its list)", limit_s=max(args.deadline, 900.0) + 60.0)
         dist.barrier()
         from havac_amd.dist import close_c_gathers
         close_c_gathers()
         dist.destroy_process_group()
+    watchdog.stop()
     if failed:
         sys.exit(f"bench.py: {failed}")
 

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhavac_dev.so")
 
 HAVAC_OK = 0
-E_LENGTH, E_LOGIC, E_RUNTIME, E_NOMEM, E_HIT_OVERFLOW, E_NO_DEVICE, E_ARGUMENT = -1, -2, -3, -4, -5, -6, -7
+E_LENGTH, E_LOGIC, E_RUNTIME, E_NOMEM, E_HIT_OVERFLOW, E_NO_DEVICE, E_ARGUMENT, E_TIMEOUT = -1, -2, -3, -4, -5, -6, -7, -8
 
 STATE_NEW, STATE_QUEUED, STATE_RUNNING, STATE_COMPLETED, STATE_ERROR = 1, 2, 3, 4, 5
 STATE_ABORT, STATE_SUBMITTED, STATE_TIMEOUT, STATE_NORESPONSE = 6, 7, 8, 9
@@ -75,6 +75,9 @@ SIGNATURES = {
     "havac_gather_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "havac_gather_counts": (C.c_int, [_vp, C.c_int64, C.c_void_p, C.c_void_p]),
     "havac_gather_records": (C.c_int, [_vp, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "havac_gather_set_deadline": (C.c_int, [_vp, C.c_uint32]),
+    "havac_gather_wait": (C.c_int, [_vp]),
+    "havac_gather_use_library": (C.c_int, [C.c_char_p]),
     "havac_gather_last_error": (C.c_char_p, [_vp]),
     "havac_gather_destroy": (None, [_vp]),
     "havac_ssv_ctx_last_error": (C.c_char_p, [_vp]),

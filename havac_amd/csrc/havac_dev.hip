@@ -1121,6 +1121,11 @@ extern "C" int havac_dev_set_tuning(havac_dev* d, const int32_t* values, uint32_
     if (d->has_run && !d->finished) { d->err = "cannot change the tuning during a run"; return HAVAC_E_LOGIC; }
     int v[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
     for (uint32_t i = 0; i < count && i < 9; i++) v[i] = values[i];
+    // everything is checked before anything is applied (the same tests the three setters make): a refused value leaves no GPU half tuned
+    if (v[2] > 2 || v[3] > 1 || (v[0] > 0 && v[0] < 1024) || v[4] > 3 || (v[6] >= 0 && v[6] < 1024) || v[7] == 0 || v[7] == 1 || v[7] > 16 || v[8] > 1) {
+        d->err = "bad tuning value";
+        return HAVAC_E_ARGUMENT;
+    }
     for (DevicePart& p : d->parts) {
         if (int rc = havac_ssv_set_tuning(p.ctx, v[0], v[1], v[2], v[3])) { d->err = havac_ssv_ctx_last_error(p.ctx); return rc; }
         if (int rc = havac_ssv_set_split_tuning(p.ctx, v[4], v[5], v[6], v[7])) { d->err = havac_ssv_ctx_last_error(p.ctx); return rc; }
@@ -1136,13 +1141,20 @@ extern "C" int havac_dev_set_tuning(havac_dev* d, const int32_t* values, uint32_
 // One GPU: nothing to overlap, nothing is locked.  If the pages cannot be locked the copies still work, staged.
 struct LockedSource {
     void* p = nullptr;
-    LockedSource(const havac_dev* d, const void* src, uint64_t nbytes) {
+    const havac_dev* dev;
+    LockedSource(const havac_dev* d, const void* src, uint64_t nbytes) : dev(d) {
         if (d->parts.size() > 1 && nbytes >= (1u << 20)) {
             if (hipHostRegister(const_cast<void*>(src), nbytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(src);
             else (void)hipGetLastError();
         }
     }
-    ~LockedSource() { if (p) (void)hipHostUnregister(p); }
+    ~LockedSource() {
+        if (!p) return;
+        // on an early error return some GPUs' copies from these pages may still be in flight: drained before the pages are unlocked
+        for (const DevicePart& part : dev->parts)
+            if (part.stream && hipSetDevice(part.device) == hipSuccess) (void)hipStreamSynchronize(part.stream);
+        (void)hipHostUnregister(p);
+    }
 };
 template <typename T>
 static int upload(havac_dev* d, T* DevicePart::*buf, uint64_t DevicePart::*alloc, const void* src, uint64_t nbytes) {

@@ -22,10 +22,13 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -50,13 +53,26 @@ struct Rccl {
     std::string error;
 };
 
+// The library to bind: librccl.so.1 unless havac_gather_use_library() named another one before the first use (rehearsals of
+// several ranks on ONE GPU, which RCCL itself refuses: tests/native/rccl_standin.cpp).  An argument, not an environment variable.
+std::mutex g_bind_mutex;
+std::string g_library_path;          // empty: RCCL
+bool g_bound = false;
+
 // bound once per process; never unloaded (communicators may outlive any one caller)
 Rccl* rccl() {
     static Rccl* const lib = [] {
         Rccl* r = new Rccl;
-        for (const char* name : {"librccl.so.1", "librccl.so"}) {
-            r->handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (r->handle) break;
+        std::string path;
+        { std::lock_guard<std::mutex> lock(g_bind_mutex); path = g_library_path; g_bound = true; }
+        if (!path.empty()) {
+            r->handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (!r->handle) { r->error = path + " could not be loaded: " + (dlerror() ? dlerror() : "?"); return r; }
+        } else {
+            for (const char* name : {"librccl.so.1", "librccl.so"}) {
+                r->handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (r->handle) break;
+            }
         }
         if (!r->handle) { r->error = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?"); return r; }
         auto bind = [&](auto& fn, const char* symbol) {
@@ -85,6 +101,8 @@ struct havac_gather {
     int64_t* h_counts = nullptr;           // pinned, same layout
     std::vector<int64_t> counts;           // of the last havac_gather_counts
     bool counted = false, broken = false;
+    bool records_pending = false;          // havac_gather_records enqueued something `after` has not been seen to pass
+    uint32_t deadline_ms = 0;              // havac_gather_set_deadline: 0 = wait without limit
     std::string err;
 };
 
@@ -105,6 +123,57 @@ struct havac_gather {
             return HAVAC_E_RUNTIME;                                                             \
         }                                                                                       \
     } while (0)
+
+extern "C" int havac_gather_use_library(const char* path) {
+    std::lock_guard<std::mutex> lock(g_bind_mutex);
+    const std::string want = path ? path : "";
+    if (g_bound) return want == g_library_path ? HAVAC_OK : HAVAC_E_LOGIC;      // bound already: one collective library per process
+    g_library_path = want;
+    return HAVAC_OK;
+}
+
+namespace {
+// Waits for `event` (recorded on the communicator's stream) for at most g->deadline_ms (0: without limit).  A collective that
+// does not complete -- a peer that died, or never reached it -- would otherwise hold this rank inside hipStreamSynchronize for
+// ever, and with it the job's other ranks: the deadline turns that into an error that names the rank and the stage.  The
+// communicator is unusable afterwards (an operation of it is still in flight: havac_gather_destroy aborts it).
+int wait_with_deadline(havac_gather* g, hipEvent_t event, const char* stage) {
+    if (g->deadline_ms == 0) {
+        hipError_t e = hipEventSynchronize(event);
+        if (e != hipSuccess) { g->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); g->broken = true; return HAVAC_E_RUNTIME; }
+        return HAVAC_OK;
+    }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(g->deadline_ms);
+    for (;;) {
+        const hipError_t q = hipEventQuery(event);
+        if (q == hipSuccess) return HAVAC_OK;
+        if (q != hipErrorNotReady) { g->err = std::string("hipEventQuery: ") + hipGetErrorString(q); g->broken = true; return HAVAC_E_RUNTIME; }
+        if (std::chrono::steady_clock::now() >= deadline) {
+            g->err = "rank " + std::to_string(g->rank) + " of " + std::to_string(g->world) + ": " + stage + " did not complete within " +
+                     std::to_string(g->deadline_ms) + " ms (a peer never reached it, or left)";
+            g->broken = true;
+            return HAVAC_E_TIMEOUT;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+}  // namespace
+
+extern "C" int havac_gather_set_deadline(havac_gather* g, uint32_t timeout_ms) {
+    if (!g) return HAVAC_E_ARGUMENT;
+    g->deadline_ms = timeout_ms;
+    return HAVAC_OK;
+}
+
+extern "C" int havac_gather_wait(havac_gather* g) {
+    if (!g) return HAVAC_E_ARGUMENT;
+    if (!g->records_pending) return HAVAC_OK;
+    if (g->broken) { g->err = "the communicator is broken (an earlier operation failed): destroy it"; return HAVAC_E_LOGIC; }
+    GATHER_HIP(g, hipSetDevice(g->device));
+    const int rc = wait_with_deadline(g, g->after, "the gather of the records (ncclSend / ncclRecv)");
+    if (rc == HAVAC_OK) g->records_pending = false;
+    return rc;
+}
 
 extern "C" int havac_gather_rccl_version(int* version) {
     Rccl* const lib = rccl();
@@ -129,8 +198,11 @@ extern "C" void havac_gather_destroy(havac_gather* g) {
     (void)hipSetDevice(g->device);
     if (g->comm) {
         // a communicator with an operation that can never complete (a peer left, a refused receive buffer) must be aborted, not drained
+        // (what is still queued gets the same deadline as any other wait: a peer that died must not hold this rank in its destructor)
+        if (!g->broken && g->stream && g->after && hipEventRecord(g->after, g->stream) == hipSuccess)
+            (void)wait_with_deadline(g, g->after, "the communicator's last operations");
         if (g->broken) (void)g->lib->CommAbort(g->comm);
-        else { if (g->stream) (void)hipStreamSynchronize(g->stream); (void)g->lib->CommDestroy(g->comm); }
+        else (void)g->lib->CommDestroy(g->comm);
     }
     if (g->before) (void)hipEventDestroy(g->before);
     if (g->after) (void)hipEventDestroy(g->after);
@@ -188,7 +260,9 @@ extern "C" int havac_gather_counts(havac_gather* g, int64_t my_count, int64_t* c
     GATHER_HIP(g, hipMemcpyAsync(g->d_counts + g->world, g->h_counts + g->world, sizeof(int64_t), hipMemcpyHostToDevice, g->stream));
     GATHER_NCCL(g, g->lib->AllGather(g->d_counts + g->world, g->d_counts, 1, ncclInt64, g->comm, g->stream));
     GATHER_HIP(g, hipMemcpyAsync(g->h_counts, g->d_counts, (size_t)g->world * sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
-    GATHER_HIP(g, hipStreamSynchronize(g->stream));
+    GATHER_HIP(g, hipEventRecord(g->after, g->stream));
+    if (const int rc = wait_with_deadline(g, g->after, "the exchange of the counts (ncclAllGather)")) return rc;
+    g->records_pending = false;            // (the stream is in order: whatever was queued before the counts has passed too)
     for (uint32_t r = 0; r < g->world; r++) counts_out[r] = g->counts[r] = g->h_counts[r];
     g->counted = true;
     return HAVAC_OK;
@@ -220,21 +294,32 @@ extern "C" int havac_gather_records(havac_gather* g, const uint64_t* d_records, 
     GATHER_HIP(g, hipStreamWaitEvent(g->stream, g->before, 0));
     if (g->world > 1) {
         GATHER_NCCL(g, g->lib->GroupStart());
+        // (a failure between GroupStart and GroupEnd must not leave the thread's group open: the group is closed first, the
+        // error reported afterwards -- the communicator is broken either way, and havac_gather_destroy aborts it)
+        ncclResult_t posted = ncclSuccess;
+        const char* what = "";
         if (g->rank != 0) {
-            if (mine) GATHER_NCCL(g, g->lib->Send(d_records, (size_t)mine, ncclUint64, 0, g->comm, g->stream));
+            if (mine) { posted = g->lib->Send(d_records, (size_t)mine, ncclUint64, 0, g->comm, g->stream); what = "ncclSend"; }
         } else {
             uint64_t offset = mine;
-            for (uint32_t r = 1; r < g->world; r++) {
+            for (uint32_t r = 1; r < g->world && posted == ncclSuccess; r++) {
                 const uint64_t n = (uint64_t)g->counts[r];
-                if (n) GATHER_NCCL(g, g->lib->Recv(d_out + offset, (size_t)n, ncclUint64, (int)r, g->comm, g->stream));
+                if (n) { posted = g->lib->Recv(d_out + offset, (size_t)n, ncclUint64, (int)r, g->comm, g->stream); what = "ncclRecv"; }
                 offset += n;
             }
         }
-        GATHER_NCCL(g, g->lib->GroupEnd());
+        const ncclResult_t closed = g->lib->GroupEnd();
+        if (posted != ncclSuccess || closed != ncclSuccess) {
+            const bool in_group = posted != ncclSuccess;
+            g->err = std::string(in_group ? what : "ncclGroupEnd") + ": " + g->lib->GetErrorString(in_group ? posted : closed);
+            g->broken = true;
+            return HAVAC_E_RUNTIME;
+        }
     }
     if (g->rank == 0 && mine && d_out != d_records)
         GATHER_HIP(g, hipMemcpyAsync(d_out, d_records, (size_t)mine * sizeof(uint64_t), hipMemcpyDeviceToDevice, g->stream));
     GATHER_HIP(g, hipEventRecord(g->after, g->stream));
     GATHER_HIP(g, hipStreamWaitEvent(caller, g->after, 0));
+    g->records_pending = true;
     return HAVAC_OK;
 }

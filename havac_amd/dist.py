@@ -29,12 +29,51 @@ rank raises afterwards, so no rank is left waiting inside a collective.
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import torch
 import torch.distributed as dist
 
 FAILED = -1      # count reported by a rank whose pass raised
+
+# How the records travel (arguments of the caller, not environment variables):
+#   route "c_abi" -- libhavac_dev.so's own RCCL calls (include/havac_dev.h level 3): the default on the nccl backend, and on any
+#                    backend once use_gather_library() has named a stand-in for RCCL (rehearsals of several ranks on one GPU);
+#   route "torch" -- torch.distributed's point-to-point operations: gloo on CPU tensors in the tests, or NCCL for comparison.
+_route = "c_abi"
+_library = None          # path handed to havac_gather_use_library, or None = librccl.so.1
+_deadline_ms = 0         # havac_gather_set_deadline of every communicator made from here on (0: none)
+
+
+def set_gather_route(route: str):
+    global _route
+    if route not in ("c_abi", "torch"):
+        raise ValueError("route: 'c_abi' or 'torch'")
+    _route = route
+
+
+def use_gather_library(path):
+    """Bind `path` instead of librccl.so.1 for the C-ABI gather (before the process's first gather; tests/native/rccl_standin.cpp
+    for several ranks on one GPU).  None = RCCL."""
+    global _library
+    from . import _lib
+    rc = _lib.load().havac_gather_use_library(path.encode() if path else None)
+    if rc != 0:
+        raise RuntimeError("a collective library is bound already: havac_gather_use_library must come before the first gather")
+    _library = path or None
+
+
+def set_gather_deadline(seconds: float):
+    """Every host wait of the C-ABI gather gives up after `seconds` (0: never) with hw_client.CollectiveTimeout naming the rank
+    and the stage, instead of holding the rank inside a collective a peer never reaches."""
+    global _deadline_ms
+    _deadline_ms = int(max(0.0, seconds) * 1000)
+    for g in _c_gathers.values():
+        if g is not None:
+            g.set_deadline(_deadline_ms)
+
+
+def _c_route(group) -> bool:
+    return _route == "c_abi" and (dist.get_backend(group) == "nccl" or _library is not None)
 
 
 class RcclGather:
@@ -81,6 +120,13 @@ class RcclGather:
     def records(self, d_records: int, d_out: int = 0, out_capacity: int = 0, stream: int = 0):
         self._check(self._L.havac_gather_records(self._h, d_records or None, d_out or None, out_capacity, stream or None))
 
+    def set_deadline(self, timeout_ms: int):
+        self._check(self._L.havac_gather_set_deadline(self._h, int(timeout_ms)))
+
+    def wait(self):
+        """for what the last records() enqueued, with the deadline"""
+        self._check(self._L.havac_gather_wait(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.havac_gather_destroy(self._h)
@@ -102,7 +148,10 @@ def c_gather(group=None):
     # inside a gather it never joins.  Where any rank fails, every rank takes torch.distributed's point-to-point route
     # (gather_hits) for good -- the same exchange, the same buffers.
     def agreed(ok: bool) -> bool:
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        on_gpu = dist.get_backend(group) == "nccl"
+        if on_gpu:      # (torch's communicator and the library's own must never have operations in flight side by side)
+            torch.cuda.synchronize()
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         return bool(flag.item())
     g, uid, why = None, None, ""
@@ -115,6 +164,8 @@ def c_gather(group=None):
     if agreed(box[0] is not None):
         try:
             g = RcclGather(rank, world, box[0])
+            if _deadline_ms:
+                g.set_deadline(_deadline_ms)
         except Exception as e:      # noqa: BLE001
             why = str(e)
         if not agreed(g is not None):
@@ -167,8 +218,8 @@ def gather_hits(local_hits: torch.Tensor, local_count: int, group=None, out: tor
     `local_count` valid; `local_count` = FAILED if this rank's pass raised).  Returns
     (records concatenated in rank order, per-rank counts) on rank 0 and (None, counts)
     elsewhere.  `out`: optional receive buffer on rank 0 (used when it is large enough)."""
-    if dist.get_backend(group) == "nccl" and os.environ.get("HAVAC_GATHER", "c_abi") != "torch" and c_gather(group) is not None:
-        # the records travel through libhavac_dev.so's own RCCL calls (HAVAC_GATHER=torch: the same exchange through
+    if _c_route(group) and c_gather(group) is not None:
+        # the records travel through libhavac_dev.so's own RCCL calls (set_gather_route("torch"): the same exchange through
         # torch.distributed's point-to-point operations, kept for comparison and taken when the C route cannot be set up
         # on every rank)
         return _gather_hits_c(local_hits, local_count, group, out)
@@ -209,6 +260,14 @@ def gather_hits(local_hits: torch.Tensor, local_count: int, group=None, out: tor
     for w in works:
         w.wait()
     return (merged.to(out_dev) if dev != out_dev else merged), counts
+
+
+TWO_STREAMS_FROM_CELLS = 4e10     # per shard: from here on consecutive passes' kernels run side by side (ShardedSsv)
+
+
+def from_cells(nsymbols, nrows, rank, world):
+    from .ssv import shard_cells
+    return shard_cells(nsymbols, nrows, rank, world)
 
 
 class _Slot:
@@ -264,12 +323,15 @@ class ShardedSsv:
         # are filled by its neighbour's first workgroups -- instead of behind its end: C2 1.878 -> 1.834 ms per step, less than
         # one kernel takes alone (1.850).  A kernel's event-timed duration then includes its neighbour's share of the chip;
         # the duration of a kernel ALONE is what a depth-1 engine measures (bench.py does, for `roofline`).
-        # kernel_streams = 1 (or HAVAC_KERNEL_STREAMS=1): one stream, kernels back to back, never side by side (rounds 2-3) --
-        # what passes of a fraction of a millisecond want: two 0.13 ms kernels side by side, each with its preparation and
-        # its tails behind it, get in each other's way (a 64-row model x 100 Mbp: 0.221 against 0.200 ms per step).
-        if kernel_streams is None:
-            kernel_streams = int(os.environ.get("HAVAC_KERNEL_STREAMS", "2"))
-        self.kernel_stream2 = torch.cuda.Stream(device, priority=high) if depth > 1 and kernel_streams > 1 else None
+        # kernel_streams = 1: one stream, kernels back to back, never side by side (rounds 2-3) -- what passes of a fraction of a
+        # millisecond want: two 0.13 ms kernels side by side, each with its preparation and its tails behind it, get in each
+        # other's way (a 64-row model x 100 Mbp: 0.221 against 0.200 ms per step; 256 rows: -4 %).  None (the default): the
+        # library's rule, per pass -- two streams from 4e10 cells per shard on (512 rows x 100 Mbp: +1.8 %, 1024 rows: +3.5 %).
+        if kernel_streams not in (None, 1, 2):
+            raise ValueError("kernel_streams: None (the library's rule), 1 or 2")
+        self.kernel_streams = kernel_streams
+        self.kernel_stream2 = torch.cuda.Stream(device, priority=high) if depth > 1 and kernel_streams != 1 else None
+        self.used_two_streams = False
         self._flip = 0
         self.in_flight = []               # slot indices, oldest first
         self.next_slot = 0
@@ -289,7 +351,9 @@ class ShardedSsv:
             raise RuntimeError("every slot is in flight: collect() first")
         slot = self.slots[self.next_slot]
         stream = self.kernel_stream if self.kernel_stream is not None else torch.cuda.current_stream(self.device)
-        if self.kernel_stream2 is not None:
+        if self.kernel_stream2 is not None and (self.kernel_streams == 2 or
+                                                from_cells(nsymbols, nrows, self.rank, self.world) >= TWO_STREAMS_FROM_CELLS):
+            self.used_two_streams = True
             self._flip ^= 1
             if self._flip:
                 stream = self.kernel_stream2
@@ -337,6 +401,16 @@ class ShardedSsv:
                 current.wait_stream(stream)
                 merged.record_stream(current)
         return merged, found
+
+    def wait_gathers(self):
+        """The records of the last collected pass may still be travelling (the gather is enqueued, not waited for): waits for
+        them with the gather's deadline (set_gather_deadline; hw_client.CollectiveTimeout names rank and stage) -- before a
+        device-wide synchronise, which a peer that died would never let return."""
+        if self.world == 1 and not self.gather_when_alone:
+            return
+        g = _c_gathers.get(None)
+        if g is not None:
+            g.wait()
 
     def gather_times(self):
         """device milliseconds of every gather so far (synchronises the events)"""

@@ -31,6 +31,11 @@ class NoDeviceError(RuntimeError):
     """No usable gfx950 device."""
 
 
+class CollectiveTimeout(RuntimeError):
+    """HAVAC_E_TIMEOUT: a collective of a sharded run did not complete before its deadline (havac_gather_set_deadline);
+    the message names the rank and the stage."""
+
+
 def raise_for(code: int, message: str):
     if code >= 0:
         return
@@ -46,6 +51,8 @@ def raise_for(code: int, message: str):
         raise NoDeviceError(message or "no gfx950 device")
     if code == _lib.E_ARGUMENT:
         raise ValueError(message or "bad argument")
+    if code == _lib.E_TIMEOUT:
+        raise CollectiveTimeout(message or "a collective did not complete before its deadline")
     raise RuntimeError(message or f"havac_dev error {code}")
 
 

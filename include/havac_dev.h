@@ -61,7 +61,9 @@ enum {
     HAVAC_E_HIT_OVERFLOW = -5, /* more hits than the hit buffer holds (the reference has a fixed 3.5 GiB
                                   buffer and no check, host/HavacHwClient.hpp:94) */
     HAVAC_E_NO_DEVICE = -6,    /* no usable gfx950 device / HIP runtime */
-    HAVAC_E_ARGUMENT = -7
+    HAVAC_E_ARGUMENT = -7,
+    HAVAC_E_TIMEOUT = -8       /* a collective of a sharded run did not complete before its deadline (havac_gather_set_deadline);
+                                  std::runtime_error.  No counterpart in the reference: one device per object */
 };
 
 /* run states, numerically equal to havac_cmd_state / ert_cmd_state
@@ -402,7 +404,17 @@ const char *havac_ssv_ctx_last_error(havac_ssv_ctx *ctx);
  *                            communicator's own low-priority stream; `hip_stream` is made to wait for it, the host is not.
  *                            d_out / out_capacity are ignored on ranks > 0.  A receive buffer that is too small is refused on
  *                            rank 0 before anything is posted (HAVAC_E_LENGTH) and leaves the communicator unusable.
- *   havac_gather_destroy     collective in the good case (ncclCommDestroy); aborts a broken communicator. */
+ *   havac_gather_destroy     collective in the good case (ncclCommDestroy); aborts a broken communicator.
+ *   havac_gather_set_deadline  every host wait of this communicator -- for the counts, in havac_gather_wait, in
+ *                            havac_gather_destroy -- gives up after timeout_ms (0, the default: never) with HAVAC_E_TIMEOUT and a
+ *                            message that names this rank and the stage: a rank that died, or never reached the collective, then
+ *                            costs the others `timeout_ms`, not the job's whole time limit.  The communicator is unusable afterwards.
+ *   havac_gather_wait        waits (with the deadline) for what the last havac_gather_records enqueued; a caller that lets the
+ *                            records travel behind its next pass calls this before it reuses the buffers or ends its timed region.
+ *   havac_gather_use_library names the collective library to bind INSTEAD of librccl.so.1, before the first havac_gather_* call
+ *                            of the process binds one (afterwards: HAVAC_E_LOGIC unless it is the same path; NULL = RCCL).  For
+ *                            rehearsals of several ranks on ONE GPU, which RCCL refuses: tests/native/rccl_standin.cpp implements
+ *                            the eleven bound entry points over shared memory.  An argument, not an environment variable. */
 #define HAVAC_GATHER_ID_BYTES 128
 typedef struct havac_gather havac_gather;
 int havac_gather_rccl_version(int *version);
@@ -410,6 +422,9 @@ int havac_gather_unique_id(uint8_t id[HAVAC_GATHER_ID_BYTES]);
 int havac_gather_create(uint32_t rank, uint32_t world, const uint8_t id[HAVAC_GATHER_ID_BYTES], havac_gather **out);
 int havac_gather_counts(havac_gather *g, int64_t my_count, int64_t *counts_out, void *hip_stream);
 int havac_gather_records(havac_gather *g, const uint64_t *d_records, uint64_t *d_out, uint64_t out_capacity, void *hip_stream);
+int havac_gather_set_deadline(havac_gather *g, uint32_t timeout_ms);
+int havac_gather_wait(havac_gather *g);
+int havac_gather_use_library(const char *path);
 const char *havac_gather_last_error(havac_gather *g);
 void havac_gather_destroy(havac_gather *g);
 

@@ -72,7 +72,9 @@ def lib():
 def build_info(reference: bool = False) -> str:
     """'<compiler> <version> <flags>' of liboracle.so, or of _ref/libsoftssv_ref.so (the reference's softSsv)"""
     L = ref() if reference else lib()
-    fn = L.softssv_ref_build_info if reference else L.havac_oracle_build_info
+    fn = getattr(L, "softssv_ref_build_info" if reference else "havac_oracle_build_info", None)
+    if fn is None:          # a library built before the symbol existed (a stale .so is not rebuilt by lib() / ref())
+        return "unknown (a stale checker library: run `make -C oracle all _ref`)"
     fn.restype = C.c_char_p
     fn.argtypes = []
     return fn().decode()

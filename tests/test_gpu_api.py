@@ -369,7 +369,7 @@ def test_native_software_testbench(tmp_path):
 
 
 @pytest.mark.parametrize("route", ["c_abi", "torch"])
-def test_rccl_gather_of_hit_records_single_rank(oracle, route, monkeypatch):
+def test_rccl_gather_of_hit_records_single_rank(oracle, route):
     """The collectives of the N > 1 path on the real backend (nccl = RCCL), as far as one GPU allows: a one-rank
     process group, gather_hits on device tensors issued from a side stream (what ShardedSsv does with passes in
     flight), then the barrier and the MAX all-reduce bench.py uses.  Route c_abi (the default on the nccl backend): the
@@ -381,7 +381,7 @@ def test_rccl_gather_of_hit_records_single_rank(oracle, route, monkeypatch):
     from havac_amd import dist as hdist
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
-    monkeypatch.setenv("HAVAC_GATHER", route)
+    hdist.set_gather_route(route)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = "29533" if route == "c_abi" else "29534"
@@ -417,6 +417,7 @@ def test_rccl_gather_of_hit_records_single_rank(oracle, route, monkeypatch):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert float(t.item()) == 1.5
     finally:
+        hdist.set_gather_route("c_abi")
         hdist.close_c_gathers()
         dist.destroy_process_group()
 
@@ -587,25 +588,31 @@ def test_bench_line_contract():
     assert d["cpu_baseline"]["vectorised_port"]["whole_hit_list_matches_gpu"] is True
 
 
-@pytest.mark.parametrize("world,rows,segments", [(2, 256, 400), (4, 1024, 150)])
-def test_bench_starts_its_own_ranks(world, rows, segments):
+@pytest.mark.parametrize("world,rows,segments,gather", [(2, 256, 400, "gloo"), (4, 1024, 150, "gloo"), (4, 1024, 150, "standin"), (3, 256, 200, "standin")])
+def test_bench_starts_its_own_ranks(world, rows, segments, gather):
     """`python bench.py --gpus N` with no launcher around it starts N ranks itself.  On
-    a one-GPU box all ranks share the card, so the records travel over gloo instead of RCCL (HAVAC_BENCH_BACKEND);
-    the launcher, the sharding, the variable-length gather and the per-rank report are the ones an 8-GPU run uses.
-    Two ranks with a 256-row model (the resident-table kernel on every shard) and four with a 1024-row one (the standard
-    kernel, a 1023-column halo on three of them, two boundary stretches checked against the CPU)."""
+    a one-GPU box all ranks share the card, which RCCL refuses: `--backend gloo`.  gather = "gloo": the records travel through
+    torch.distributed over gloo; gather = "standin" (round 5): through libhavac_dev.so's OWN gather (havac_gather_*: the route a
+    run on real GPUs takes) bound to tests/native/librccl_standin.so -- the launcher, the sharding, two passes in flight with
+    the gather behind the next kernel, the variable-length exchange, the deadline and the per-rank report are then the ones
+    an 8-GPU run uses, only librccl itself is not.  Two ranks with a 256-row model (the resident-table kernel on every shard)
+    and four with a 1024-row one (the standard kernel, a 1023-column halo on three of them, two boundary stretches checked
+    against the CPU)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HAVAC_BENCH_BACKEND="gloo")
-    if world == 4:
-        env["HAVAC_KERNEL_STREAMS"] = "2"      # consecutive passes' kernels side by side, as a full-size run has them (these shards are too small to choose it)
+    env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
-                        "--rows", str(rows), "--columns-per-gpu", str(segments * synth.SEGMENT)],
-                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+           "--rows", str(rows), "--columns-per-gpu", str(segments * synth.SEGMENT), "--backend", "gloo"]
+    if world == 4:
+        cmd += ["--kernel-streams", "2"]      # consecutive passes' kernels side by side, as a full-size run has them (these shards are too small to choose it)
+    if gather == "standin":
+        from test_gpu_gather_ranks import build_standin
+        cmd += ["--gather-library", build_standin()]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -613,10 +620,12 @@ def test_bench_starts_its_own_ranks(world, rows, segments):
     assert d["n_gpus"] == world and d["config"]["columns"] == world * segments * synth.SEGMENT
     dd = d["distributed"]
     assert dd["world"] == world and dd["backend"] == "gloo" and len(dd["per_rank"]) == world
+    assert ("havac_gather_*" in dd["gather"] and "librccl_standin.so" in dd["gather"]) == (gather == "standin"), dd["gather"]
     assert [p["rank"] for p in dd["per_rank"]] == list(range(world))
     assert dd["per_rank"][0]["halo_cells"] == 0 and all(p["halo_cells"] == (rows - 1) * rows // 2 for p in dd["per_rank"][1:])
     assert d["kernel"]["name"] == ("ssv_resident_kernel" if rows <= 256 else "ssv_diag_kernel")
     assert d["config"]["passes_in_flight"] == 2 and d["config"]["kernel_streams"] == (2 if world == 4 else 1)
+    assert "strictly serial" in d["config"]["api_path"]
     assert sum(p["records"] for p in dd["per_rank"]) == d["config"]["hits_per_step"]
     assert all(p["kernel_ms"] > 0 for p in dd["per_rank"])
     # rank 0 has checked the gathered list before printing: order, counts, columns per rank, the records around the cut
@@ -625,3 +634,31 @@ def test_bench_starts_its_own_ranks(world, rows, segments):
     assert len(parity["boundary_stretches"]) == min(2, world - 1) and parity["boundary_stretches"][0]["boundary_column"] == segments * synth.SEGMENT
     assert all(b["equals_cpu_checker"] and b["records"] > 0 for b in parity["boundary_stretches"])
     assert d["clock_warmup_passes"] >= 3
+
+
+@pytest.mark.parametrize("how", ["exit", "hang"])
+def test_a_rank_that_dies_or_hangs_ends_the_job(how):
+    """nothing in the N > 1 path had a deadline -- a rank that died or hung left the others inside a
+    collective until the driver's limit.  Three ranks on one GPU over the C-ABI gather (stand-in library); in the middle of the
+    timed region rank 2 leaves without a word (`--die-at 2:3`, a test hook of bench.py: os._exit) or stops making calls
+    (`2:3:hang`).  The job must end non-zero well inside the test's limit; a hung rank is named, with its stage, by the
+    watchdogs (`--deadline 8`).  (The deadline of the gather's own host waits: tests/test_gpu_gather_ranks.py.)"""
+    import os
+    import subprocess
+    import sys
+    import time
+    from test_gpu_gather_ranks import build_standin
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "6", "--warmup", "1", "--rows", "256",
+                        "--columns-per-gpu", str(100 * synth.SEGMENT), "--backend", "gloo", "--gather-library", build_standin(),
+                        "--deadline", "8", "--die-at", "2:3" + (":hang" if how == "hang" else ""), "--no-pmc"],
+                       capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    took = time.time() - t0
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]          # no result line from a broken job
+    if how == "hang":
+        assert "has been in stage 'timed region: pass 3 of 6'" in r.stderr and "giving up, exit code 3" in r.stderr, r.stderr[-3000:]
+    assert took < 240, took
