@@ -296,6 +296,10 @@ int plan_launch(std::string& err, const Tiling& t, uint32_t tb, uint32_t te, int
     return HAVAC_OK;
 }
 
+// the control words of a context (havac_ssv_ctx::control)
+constexpr uint32_t kControlTickets = 0, kControlFault = kTicketCounters * kTicketStride, kControlOrderState = (kTicketCounters + 1) * kTicketStride,
+                   kControlWords = kControlOrderState + sizeof(OrderState) / sizeof(uint32_t);
+
 // hand-off slots of a launch with cut tiles (ssv_kernels.hip.h, "items": slot = partition * split_units + unit, or the tile's
 // number where every tile is cut)
 inline size_t handoff_slots(const SsvRare& L) {
@@ -314,29 +318,31 @@ struct havac_ssv_ctx {
     uint32_t* rows8 = nullptr; size_t rows8_rows = 0;   // padded copy of the model
     uint32_t* chunk_flags = nullptr; size_t chunk_flag_words = 0;   // one bit per 32-row chunk: hit test every four steps allowed
     // work distribution of the persistent kernel (ssv_kernels.hip.h, SsvLaunch)
-    uint32_t* tickets = nullptr;                                    // kTicketCounters counters + the fault word
+    // the words a pass's kernels count in, cleared by ssv_prepare_model in front of every pass: [0, 144) the ticket counters of cut
+    // tiles and the fault word, [144, 160) the ordering's OrderState (hit_order.hip.h)
+    uint32_t* control = nullptr;
     uint32_t* block_flags = nullptr; size_t block_flag_tiles = 0;   // row-split launches: row blocks finished, per tile
     uint32_t* block_state = nullptr; size_t block_state_tiles = 0;  // row-split launches: 16 x 64 scores per tile
     uint64_t* tails = nullptr; uint32_t* tail_counts = nullptr; size_t tail_blocks = 0;   // block tails (ssv_kernels.hip.h): kTailSlots keys + a count per block
-    int resident_blocks = 0;                                        // blocks the device holds at once (5 per CU)
+    int resident_blocks = 0;                                        // blocks the device holds at once (6 per CU)
     const uint16_t* pair_mask = nullptr;                // optional separator bitmap (boundary mode), caller-owned
     void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     uint64_t* sort_alt = nullptr; size_t sort_alt_count = 0;
-    // bucket ordering (hit_order.hip.h): per bucket a count / cursor and an offset, the list of large buckets, shared state
+    // the ordering (hit_order.hip.h, ssv_order_pass): per bucket a count / cursor and an offset, the list of large buckets
     uint32_t* bucket_counts = nullptr; uint32_t* bucket_offsets = nullptr; uint64_t* bucket_chunk_base = nullptr;
     uint32_t* bucket_large = nullptr; size_t bucket_alloc = 0;
-    OrderState* order_state = nullptr;         // device: two sets used alternately (the last kernel of a pass clears the other set)
-    unsigned order_parity = 0;
-    OrderState* h_order_state = nullptr;       // pinned copy the host reads after the ordering
-    bool bucket_ordered = false;               // the pending pass went through the bucket ordering (else: the radix sort)
-    bool order_dirty = false;                  // an ordering was enqueued and never seen to finish: its counts and state words cannot be trusted
-    uint64_t order_count = 0;                  // records of the pending pass's ordering
+    uint32_t large_capacity = kLargeBucketDefault;   // keys the ordering kernel's LDS sorter holds in the next launch (grown on demand)
+    PassReport* h_report = nullptr;            // pinned: what the pass's ordering kernel tells the host
+    OrderPass order_args{};                    // of the pending pass (a relaunch after growing a buffer reuses them)
+    uint32_t order_tail_blocks = 0;            // blocks whose tails the pending pass's ordering gathers first (0: no tails in use)
+    uint64_t last_found = 0;                   // records of the last finished pass: sizes the next pass's ordering grids
+    bool tails_gathered = false;               // ... and whether that has been enqueued (a relaunch of the ordering must not gather twice)
+    bool order_dirty = false;                  // an ordering was cut short: its counts cannot be trusted, the next pass starts from zeroed ones
     uint64_t first_segment = 0, nsegments = 0; // the shard's segments (bucket numbering)
     int tune_ordering = -1;                    // -1 / 1: bucket ordering, 0: always the radix sort (experiments, tests)
     uint32_t last_order_buckets = 0, last_order_largest = 0; int last_order_path = 0;   // what the last pass's ordering did (tests, tools)
     unsigned long long* d_count = nullptr;
-    unsigned long long* h_count = nullptr;     // pinned
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pass start, kernel start, kernel end, records ordered, count on the host
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // pass start, kernel start, kernel end, records ordered
     CellRecord* trace_cells = nullptr; uint32_t trace_row0 = 0, trace_rows = 0, trace_cols = 0; uint64_t trace_col0 = 0;   // per-cell trace window (debugging)
     hipStream_t order_stream = nullptr;        // optional: where finish() orders the records (default: the enqueue's stream)
     uint64_t window_first = 0, window_columns = 0;   // the caller's sequence buffer holds only these columns (0, 0: all of them)
@@ -349,7 +355,7 @@ struct havac_ssv_ctx {
     uint32_t last_plan_blocks = 0, last_plan_item_rows = 0;
     int tune_parts_log2 = -1; uint32_t tune_split_rounds_x4 = kSplitRoundsX4, tune_short_rows = kShortRows, tune_guide = kCutGuide;
     // the pass enqueue() started and finish() completes
-    bool pending = false, ordering = false;    // enqueue() done; finish_begin() done
+    bool pending = false;                      // enqueue() done
     uint64_t found = 0;
     hipStream_t stream = nullptr;
     uint64_t* d_hits = nullptr;
@@ -377,19 +383,17 @@ extern "C" int havac_ssv_ctx_create(havac_ssv_ctx** out) {
     auto fail = [&](int code) { havac_ssv_ctx_destroy(c); return code; };
     if (hipGetDevice(&c->device) != hipSuccess) return fail(HAVAC_E_NO_DEVICE);
     if (hipMalloc(&c->d_count, sizeof(unsigned long long)) != hipSuccess) return fail(HAVAC_E_NOMEM);
-    if (hipMalloc(&c->tickets, (kTicketCounters + 1) * kTicketStride * sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_NOMEM);
-    if (hipMemset(c->tickets, 0, (kTicketCounters + 1) * kTicketStride * sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+    if (hipMalloc(&c->control, kControlWords * sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_NOMEM);
+    if (hipMemset(c->control, 0, kControlWords * sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_RUNTIME);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return fail(HAVAC_E_NO_DEVICE);
         c->resident_blocks = prop.multiProcessorCount * kBlocksPerCu;
     }
-    if (hipHostMalloc(&c->h_count, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return fail(HAVAC_E_NOMEM);
-    c->h_count[0] = c->h_count[1] = 0;
-    if (hipMalloc(&c->order_state, 2 * sizeof(OrderState)) != hipSuccess) return fail(HAVAC_E_NOMEM);
-    if (hipMemset(c->order_state, 0, 2 * sizeof(OrderState)) != hipSuccess) return fail(HAVAC_E_RUNTIME);
-    if (hipHostMalloc(&c->h_order_state, sizeof(OrderState), hipHostMallocDefault) != hipSuccess) return fail(HAVAC_E_NOMEM);
-    std::memset(c->h_order_state, 0, sizeof(OrderState));
+    if (hipHostMalloc(&c->h_report, sizeof(PassReport), hipHostMallocDefault) != hipSuccess) return fail(HAVAC_E_NOMEM);
+    std::memset(c->h_report, 0, sizeof(PassReport));
+    // (the ordering kernel's LDS sorter may be asked for 64 KB of dynamic LDS: above the default limit together with its few static words)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ssv_order_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLargeBucket * sizeof(uint32_t)));
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) return fail(HAVAC_E_RUNTIME);
     // the fills above ran on the null stream; passes run on streams of the caller's, possibly non-blocking ones
@@ -402,7 +406,7 @@ extern "C" void havac_ssv_ctx_destroy(havac_ssv_ctx* c) {
     if (!c) return;
     if (c->rows8) (void)hipFree(c->rows8);
     if (c->chunk_flags) (void)hipFree(c->chunk_flags);
-    if (c->tickets) (void)hipFree(c->tickets);
+    if (c->control) (void)hipFree(c->control);
     if (c->block_flags) (void)hipFree(c->block_flags);
     if (c->block_state) (void)hipFree(c->block_state);
     if (c->tails) (void)hipFree(c->tails);
@@ -413,10 +417,8 @@ extern "C" void havac_ssv_ctx_destroy(havac_ssv_ctx* c) {
     if (c->bucket_offsets) (void)hipFree(c->bucket_offsets);
     if (c->bucket_chunk_base) (void)hipFree(c->bucket_chunk_base);
     if (c->bucket_large) (void)hipFree(c->bucket_large);
-    if (c->order_state) (void)hipFree(c->order_state);
-    if (c->h_order_state) (void)hipHostFree(c->h_order_state);
+    if (c->h_report) (void)hipHostFree(c->h_report);
     if (c->d_count) (void)hipFree(c->d_count);
-    if (c->h_count) (void)hipHostFree(c->h_count);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
@@ -499,6 +501,9 @@ extern "C" int havac_ssv_set_split_tuning(havac_ssv_ctx* c, int parts_log2, int 
 }
 
 static int check_inputs(std::string& err, uint64_t nsymbols, uint32_t nrows);
+static int ensure_alt(havac_ssv_ctx* c, uint64_t count, hipStream_t stream);
+static int ensure_buckets(havac_ssv_ctx* c, uint32_t nbuckets, hipStream_t stream);
+static int launch_ordering(havac_ssv_ctx* c, unsigned seg_bits);
 extern "C" int havac_ssv_plan(uint64_t nsymbols, uint32_t nrows, uint32_t shard_index, uint32_t shard_count, uint32_t wave_slots,
                               const int32_t* tuning, uint32_t ntuning, havac_launch_plan* out) {
     static_assert(kMaxRowCuts + 1 == 33, "havac_launch_plan::row_cut");
@@ -636,15 +641,6 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     }
     const uint16_t* const pair_mask = c->pair_mask ? c->pair_mask - (c->window_columns ? c->window_first / 32 : 0) : nullptr;
 
-    HIP_TRY(c->err, hipEventRecord(c->ev[0], stream));
-    // one launch: the padded copy of the model, the chunk flags, the cleared hit counter.  (Separator pairs score -128 twice
-    // in a row whatever the model says: with a mask there are no flags, every chunk tests every two steps.)
-    {
-        const uint32_t nflagwords = c->pair_mask ? 0u : flag_words;
-        const uint32_t threads = std::max(model_words, nflagwords * 32u);
-        hipLaunchKernelGGL(ssv_prepare_model, dim3((threads + 255) / 256), dim3(256), 0, stream, d_phmm, nrows, c->rows8, model_words,
-                           t.nrows_padded, c->chunk_flags, nflagwords, c->d_count);
-    }
     // sort key = segment | row | column in segment, each field only as wide as this problem needs
     unsigned row_bits = 1, seg_bits = 1;
     while ((1u << row_bits) < t.nrows_padded + 2u) row_bits++;
@@ -666,53 +662,69 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     }
     const uint32_t nblocks = c->last_plan_blocks, largest_item_rows = c->last_plan_item_rows;
     const bool split = L.split_units != 0;
-    if (te > tb) {
-        if (split) {
-            // one hand-off slot (a count word + 2 KB of scores) per CUT tile -- the last split_units tiles of every partition, or
-            // every tile -- not per tile of the launch (a 3 Gbp genome against a tall model is 1.5 M tiles of
-            // which ~9,000 are cut; the fill below runs on every pass)
-            const size_t slots_needed = handoff_slots(L);
-            if (c->block_flag_tiles < slots_needed) {
-                HIP_TRY(c->err, hipStreamSynchronize(stream));        // an earlier pass on this stream may still use the old buffers
-                if (c->block_flags) (void)hipFree(c->block_flags);
-                if (c->block_state) (void)hipFree(c->block_state);
-                c->block_flags = c->block_state = nullptr; c->block_flag_tiles = c->block_state_tiles = 0;
-                HIP_TRY(c->err, hipMalloc(&c->block_flags, slots_needed * sizeof(uint32_t)));
-                HIP_TRY(c->err, hipMalloc(&c->block_state, slots_needed * (kRegs / 2) * 64 * sizeof(uint32_t)));
-                c->block_flag_tiles = c->block_state_tiles = slots_needed;
-            }
-            HIP_TRY(c->err, hipMemsetD32Async((hipDeviceptr_t)c->block_flags, 0, slots_needed, stream));
-            HIP_TRY(c->err, hipMemsetD32Async((hipDeviceptr_t)c->tickets, 0, kTicketCounters * kTicketStride, stream));
+    // ---- the buffers a pass needs, BEFORE anything is enqueued: growing one waits for what the stream still holds -------------------
+    size_t handoff_words = 0;
+    if (te > tb && split) {
+        // one hand-off slot (a count word + 2 KB of scores) per CUT tile -- the last split_units tiles of every partition, or
+        // every tile -- not per tile of the launch (a 3 Gbp genome against a tall model is 1.5 M tiles of
+        // which ~9,000 are cut; the counts are cleared on every pass, by ssv_prepare_model)
+        const size_t slots_needed = handoff_slots(L);
+        if (c->block_flag_tiles < slots_needed) {
+            HIP_TRY(c->err, hipStreamSynchronize(stream));        // an earlier pass on this stream may still use the old buffers
+            if (c->block_flags) (void)hipFree(c->block_flags);
+            if (c->block_state) (void)hipFree(c->block_state);
+            c->block_flags = c->block_state = nullptr; c->block_flag_tiles = c->block_state_tiles = 0;
+            HIP_TRY(c->err, hipMalloc(&c->block_flags, slots_needed * sizeof(uint32_t)));
+            HIP_TRY(c->err, hipMalloc(&c->block_state, slots_needed * (kRegs / 2) * 64 * sizeof(uint32_t)));
+            c->block_flag_tiles = c->block_state_tiles = slots_needed;
         }
+        handoff_words = slots_needed;
+    }
+    // block tails: a side buffer of kTailSlots keys per block, where blocks are short-lived -- items of up to 512 rows: a
+    // block of C2 (1024 rows) lives 200 us and loses nothing to the one atomic at its end, while its tail would cross
+    // HBM three times instead of once (measured: the same step time, 43.8 against 39.2 MB of traffic per launch) -- and
+    // the buffer stays below 128 MB
+    bool use_tails = te > tb && largest_item_rows <= 512 && (uint64_t)nblocks * kTailSlots * sizeof(uint64_t) <= (128ull << 20);
+    if (te > tb && c->tune_block_tails >= 0)      // experiments: 0 = off, 1 = the default rule, 2 = on whatever the height of an item
+        use_tails = c->tune_block_tails == 2 ? (uint64_t)nblocks * kTailSlots * sizeof(uint64_t) <= (128ull << 20) : use_tails && c->tune_block_tails != 0;
+    if (use_tails && c->tail_blocks < nblocks) {
+        HIP_TRY(c->err, hipStreamSynchronize(stream));        // an earlier pass on this stream may still use the old buffers
+        if (c->tails) (void)hipFree(c->tails);
+        if (c->tail_counts) (void)hipFree(c->tail_counts);
+        c->tails = nullptr; c->tail_counts = nullptr; c->tail_blocks = 0;
+        const size_t want = (size_t)nblocks + nblocks / 4 + 64;
+        HIP_TRY(c->err, hipMalloc(&c->tails, want * kTailSlots * sizeof(uint64_t)));
+        HIP_TRY(c->err, hipMalloc(&c->tail_counts, want * sizeof(uint32_t)));
+        c->tail_blocks = want;
+    }
+    // the ordering's second buffer and bucket tables: a first guess here, grown by finish() when the kernel says a pass needs more
+    if (hit_capacity) {
+        if (int rc2 = ensure_alt(c, std::min<uint64_t>(hit_capacity, 1ull << 22), stream)) return rc2;
+        if (int rc2 = ensure_buckets(c, 1u << 16, stream)) return rc2;
+    }
+    if (c->order_dirty && c->bucket_counts) {     // an earlier ordering was cut short: its counts cannot be trusted
+        HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, c->bucket_alloc * sizeof(uint32_t), stream));
+        c->order_dirty = false;
+    }
+
+    HIP_TRY(c->err, hipEventRecord(c->ev[0], stream));
+    // one launch: the padded copy of the model, the chunk flags, and everything the pass's kernels count in, cleared -- the hit
+    // counter, the tickets, the tails' sums, the ordering's barrier words, the hand-off counts of cut tiles.  (Separator pairs
+    // score -128 twice in a row whatever the model says: with a mask there are no flags, every chunk tests every two steps.)
+    {
+        const uint32_t nflagwords = c->pair_mask ? 0u : flag_words;
+        const uint32_t threads = std::max(std::max(model_words, nflagwords * 32u), kControlWords);
+        hipLaunchKernelGGL(ssv_prepare_model, dim3((threads + 255) / 256), dim3(256), 0, stream, d_phmm, nrows, c->rows8, model_words,
+                           t.nrows_padded, c->chunk_flags, nflagwords, c->d_count, c->control, kControlWords, c->block_flags, (uint32_t)handoff_words);
     }
     HIP_TRY(c->err, hipEventRecord(c->ev[1], stream));
-    bool tails_in_use = false;
     if (te > tb) {
         SsvRare& R = L;
         R.hits = d_hits; R.hit_count = c->d_count; R.hit_capacity = hit_capacity;
         R.col_begin = (int64_t)col_begin; R.col_span = col_end - col_begin;
-        R.abort_flag = d_abort_flag; R.pair_mask = pair_mask; R.tickets = c->tickets; R.block_flags = c->block_flags; R.block_state = c->block_state;
-        R.fault = c->tickets + kTicketCounters * kTicketStride; R.row_bits = row_bits;
-        // block tails: a side buffer of kTailSlots keys per block, where blocks are short-lived -- items of up to 512 rows: a
-        // block of C2 (1024 rows) lives 200 us and loses nothing to the one atomic at its end, while its tail would cross
-        // HBM three times instead of once (measured: the same step time, 43.8 against 39.2 MB of traffic per launch) -- and
-        // the buffer stays below 128 MB
-        const uint32_t item_rows = largest_item_rows;
-        bool use_tails = item_rows <= 512 && (uint64_t)nblocks * kTailSlots * sizeof(uint64_t) <= (128ull << 20);
-        if (c->tune_block_tails >= 0)      // experiments: 0 = off, 1 = the default rule, 2 = on whatever the height of an item
-            use_tails = c->tune_block_tails == 2 ? (uint64_t)nblocks * kTailSlots * sizeof(uint64_t) <= (128ull << 20) : use_tails && c->tune_block_tails != 0;
-        if (use_tails && c->tail_blocks < nblocks) {
-            HIP_TRY(c->err, hipStreamSynchronize(stream));        // an earlier pass on this stream may still use the old buffers
-            if (c->tails) (void)hipFree(c->tails);
-            if (c->tail_counts) (void)hipFree(c->tail_counts);
-            c->tails = nullptr; c->tail_counts = nullptr; c->tail_blocks = 0;
-            const size_t want = (size_t)nblocks + nblocks / 4 + 64;
-            HIP_TRY(c->err, hipMalloc(&c->tails, want * kTailSlots * sizeof(uint64_t)));
-            HIP_TRY(c->err, hipMalloc(&c->tail_counts, want * sizeof(uint32_t)));
-            c->tail_blocks = want;
-        }
+        R.abort_flag = d_abort_flag; R.pair_mask = pair_mask; R.tickets = c->control + kControlTickets; R.block_flags = c->block_flags; R.block_state = c->block_state;
+        R.fault = c->control + kControlFault; R.row_bits = row_bits;
         R.tails = use_tails ? c->tails : nullptr; R.tail_counts = use_tails ? c->tail_counts : nullptr;
-        tails_in_use = use_tails;
         R.cells = c->trace_cells; R.cell_row0 = c->trace_row0; R.cell_col0 = (int64_t)c->trace_col0;
         R.cell_rows = c->trace_rows; R.cell_cols = c->trace_cols;
         const uint32_t* const safe_chunks = c->pair_mask ? (const uint32_t*)nullptr : (const uint32_t*)c->chunk_flags;
@@ -728,22 +740,17 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
                                d_sequence, (const uint32_t*)c->rows8, safe_chunks, (int64_t)nsymbols, t.nrows_padded);
     }
     HIP_TRY(c->err, hipEventRecord(c->ev[2], stream));
-    // What follows the kernel -- the gather of the block tails and the copy of the count -- runs on the ordering stream
-    // when there is one: the kernel stream is then free for the next pass's kernel at once.
-    const hipStream_t after = c->order_stream ? c->order_stream : stream;
-    if (after != stream) HIP_TRY(c->err, hipStreamWaitEvent(after, c->ev[2], 0));
-    if (te > tb && tails_in_use)
-        hipLaunchKernelGGL(ssv_gather_tails, dim3((nblocks + kGatherBlocks - 1) / kGatherBlocks), dim3(256), 0, after, (const uint64_t*)c->tails,
-                           (const uint32_t*)c->tail_counts, nblocks, d_hits, c->d_count, hit_capacity);
-    HIP_TRY(c->err, hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, after));
-    // the kernel's fault word (a row-block hand-off that never came): never expected, but never waited for silently either
-    HIP_TRY(c->err, hipMemcpyAsync(c->h_count + 1, c->tickets + kTicketCounters * kTicketStride, sizeof(uint32_t), hipMemcpyDeviceToHost, after));
-    HIP_TRY(c->err, hipEventRecord(c->ev[4], after));       // finish() waits for THIS, not for the stream: later passes may be queued behind it
-    HIP_TRY(c->err, hipGetLastError());
+    // The third and last launch of the pass, the ordering (hit_order.hip.h: the count is read on the device, the tails where they
+    // lie), runs on the ordering stream when there is one: the kernel stream is then free for the next pass's kernel at once.
     c->pending = true; c->stream = stream; c->d_hits = d_hits; c->hit_capacity = hit_capacity;
     c->row_bits = row_bits;
     c->key_bits = 14 + row_bits + seg_bits;
     c->first_segment = col_begin / HAVAC_SEGMENT_COLUMNS; c->nsegments = (col_end - col_begin) / HAVAC_SEGMENT_COLUMNS;
+    c->order_tail_blocks = use_tails ? nblocks : 0u; c->tails_gathered = false;
+    const hipStream_t after = c->order_stream ? c->order_stream : stream;
+    if (after != stream) { if (hipError_t e = hipStreamWaitEvent(after, c->ev[2], 0); e != hipSuccess) { c->pending = false; c->err = hip_msg("hipStreamWaitEvent", e); return HAVAC_E_RUNTIME; } }
+    if (int orc = launch_ordering(c, seg_bits)) { c->pending = false; return orc; }
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) { c->pending = false; c->err = hip_msg("launching the pass", e); return HAVAC_E_RUNTIME; }
     return HAVAC_OK;
 }
 
@@ -770,10 +777,9 @@ static int sort_run(havac_ssv_ctx* c, uint64_t* keys, uint64_t* alt, uint64_t co
     return HAVAC_OK;
 }
 
-static int ensure_alt(havac_ssv_ctx* c, uint64_t count);
 static int sort_keys(havac_ssv_ctx* c, uint64_t* keys, uint64_t count, hipStream_t stream, unsigned key_bits = 64) {
     if (count < 2) return HAVAC_OK;
-    if (int rc = ensure_alt(c, count)) return rc;
+    if (int rc = ensure_alt(c, count, stream)) return rc;
     // (rocPRIM orders more than 2^32 keys in one call: 4.5e9 checked, tools/big_sort_check.py)
     int rc = sort_run(c, keys, c->sort_alt, count, stream, key_bits);
     if (rc) return rc;
@@ -781,17 +787,35 @@ static int sort_keys(havac_ssv_ctx* c, uint64_t* keys, uint64_t count, hipStream
     return HAVAC_OK;
 }
 
-// finish = begin (wait for the count, enqueue the ordering) + end (wait for the ordering).  A caller with several contexts --
-// several GPUs behind one handle -- begins all of them before it ends any: the orderings then run side by side instead
-// of one after the other with a host wait in between.
 // ---- ordering ------------------------------------------------------------------------------------------------------------
-static int ensure_alt(havac_ssv_ctx* c, uint64_t count) {
+static int ensure_alt(havac_ssv_ctx* c, uint64_t count, hipStream_t stream) {
     if (c->sort_alt_count >= count) return HAVAC_OK;
+    HIP_TRY(c->err, hipStreamSynchronize(stream));            // an earlier pass on this stream may still use the old one
     if (c->sort_alt) (void)hipFree(c->sort_alt);
     c->sort_alt = nullptr; c->sort_alt_count = 0;
     const size_t want = (size_t)count + count / 4 + 1024;
     HIP_TRY(c->err, hipMalloc(&c->sort_alt, want * sizeof(uint64_t)));
     c->sort_alt_count = want;
+    return HAVAC_OK;
+}
+
+static int ensure_buckets(havac_ssv_ctx* c, uint32_t nbuckets, hipStream_t stream) {
+    if (c->bucket_alloc >= nbuckets) return HAVAC_OK;
+    HIP_TRY(c->err, hipStreamSynchronize(stream));
+    if (c->bucket_counts) (void)hipFree(c->bucket_counts);
+    if (c->bucket_offsets) (void)hipFree(c->bucket_offsets);
+    if (c->bucket_chunk_base) (void)hipFree(c->bucket_chunk_base);
+    if (c->bucket_large) (void)hipFree(c->bucket_large);
+    c->bucket_counts = nullptr; c->bucket_offsets = nullptr; c->bucket_chunk_base = nullptr; c->bucket_large = nullptr; c->bucket_alloc = 0;
+    const size_t want = (size_t)nbuckets + nbuckets / 4 + 1024;
+    HIP_TRY(c->err, hipMalloc(&c->bucket_counts, want * sizeof(uint32_t)));
+    HIP_TRY(c->err, hipMalloc(&c->bucket_offsets, want * sizeof(uint32_t)));
+    HIP_TRY(c->err, hipMalloc(&c->bucket_chunk_base, (want / kScanChunk + 2) * sizeof(uint64_t)));
+    HIP_TRY(c->err, hipMalloc(&c->bucket_large, want * sizeof(uint32_t)));
+    // once: every pass leaves the counts at zero.  (On the pass's own stream: a null-stream hipMemset is not ordered against a
+    // non-blocking stream, and the kernels would race with it.)
+    HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, want * sizeof(uint32_t), stream));
+    c->bucket_alloc = want;
     return HAVAC_OK;
 }
 
@@ -805,123 +829,101 @@ static int order_by_radix_sort(havac_ssv_ctx* c, uint64_t* d_hits, uint64_t coun
     return HAVAC_OK;
 }
 
-// The queue's `count` sort keys -> the reference's records in device order, on `stream` (hit_order.hip.h).  Buckets are
-// runs of consecutive key values, (key >> shift): whole segments when segments hold few records (C2: 124 each), ranges
-// of 2^k rows of a segment when they hold many (C3: 54,800 each), chosen so that a bucket holds kTargetBucket records on
-// average.  Returns with the work enqueued; finish_end() looks at the `oversized` word afterwards.
-static int order_records(havac_ssv_ctx* c, uint64_t* d_hits, uint64_t count, hipStream_t stream) {
-    c->bucket_ordered = false; c->order_count = count;
-    c->last_order_buckets = 0; c->last_order_largest = 0; c->last_order_path = 0;
-    if (count == 0) return HAVAC_OK;
-    const unsigned row_bits = c->row_bits;
-    // how many row ranges per segment: enough for kTargetBucket records per bucket on average, and enough for the low bits of
-    // a key inside a bucket to fit 32 bits (14 column bits + at most 18 row bits)
-    unsigned split_bits = 0;
-    const uint64_t per_segment = count / std::max<uint64_t>(c->nsegments, 1);
-    while (split_bits < row_bits && (per_segment >> split_bits) > kTargetBucket) split_bits++;
-    if (row_bits > 18 && split_bits < row_bits - 18) split_bits = row_bits - 18;
-    const unsigned shift = 14 + row_bits - split_bits;
-    const uint64_t nbuckets64 = c->nsegments << split_bits;
-    if (c->tune_ordering == 0 || count < 2 || nbuckets64 >= (1ull << 27)) return order_by_radix_sort(c, d_hits, count, stream);
-    const uint32_t nbuckets = (uint32_t)nbuckets64;
-    const uint64_t base = c->first_segment << split_bits;
-    int rc = ensure_alt(c, count);
-    if (rc) return rc;
-    if (c->bucket_alloc < nbuckets) {
-        HIP_TRY(c->err, hipStreamSynchronize(stream));
-        if (c->bucket_counts) (void)hipFree(c->bucket_counts);
-        if (c->bucket_offsets) (void)hipFree(c->bucket_offsets);
-        if (c->bucket_chunk_base) (void)hipFree(c->bucket_chunk_base);
-        if (c->bucket_large) (void)hipFree(c->bucket_large);
-        c->bucket_counts = nullptr; c->bucket_offsets = nullptr; c->bucket_chunk_base = nullptr; c->bucket_large = nullptr; c->bucket_alloc = 0;
-        const size_t want = (size_t)nbuckets + nbuckets / 4 + 1024;
-        HIP_TRY(c->err, hipMalloc(&c->bucket_counts, want * sizeof(uint32_t)));
-        HIP_TRY(c->err, hipMalloc(&c->bucket_offsets, want * sizeof(uint32_t)));
-        HIP_TRY(c->err, hipMalloc(&c->bucket_chunk_base, (want / kScanChunk + 2) * sizeof(uint64_t)));
-        HIP_TRY(c->err, hipMalloc(&c->bucket_large, want * sizeof(uint32_t)));
-        // once: every pass leaves the counts at zero.  (On the pass's own stream: a null-stream hipMemset is not ordered against a
-        // non-blocking stream, and the count kernel below would race with it.)
-        HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, want * sizeof(uint32_t), stream));
-        c->bucket_alloc = want;
+// The pass's ordering kernel (hit_order.hip.h: ssv_order_pass), enqueued behind the SSV kernel with what the context holds NOW;
+// finish() launches it again when the kernel reports that a buffer was too small for this pass.  A persistent grid that is
+// resident at once: one workgroup per CU where passes run beside each other (what an SSV kernel leaves free), more when the
+// pass has the chip to itself.
+static int launch_ordering(havac_ssv_ctx* c, unsigned seg_bits) {
+    const hipStream_t after = c->order_stream ? c->order_stream : c->stream;
+    OrderPass& a = c->order_args;
+    a.hits = c->d_hits; a.alt = c->sort_alt; a.alt_capacity = c->sort_alt_count; a.capacity = c->hit_capacity;
+    a.hit_count = c->d_count;
+    a.counts = c->bucket_counts; a.offsets = c->bucket_offsets; a.chunk_base = c->bucket_chunk_base; a.large_list = c->bucket_large;
+    a.max_buckets = (uint32_t)std::min<size_t>(c->bucket_alloc, 1u << 27);
+    a.state = reinterpret_cast<OrderState*>(c->control + kControlOrderState);
+    a.host = c->h_report; a.ssv_fault = c->control + kControlFault;
+    a.row_bits = c->row_bits; a.seg_bits = seg_bits; a.large_capacity = c->large_capacity;
+    a.generic = (c->tune_ordering == 0 || c->hit_capacity == 0 || !c->sort_alt || !c->bucket_counts) ? 1u : 0u;
+    a.first_segment = c->first_segment; a.nsegments = c->nsegments;
+    // what the blocks left in their tails joins the queue first (short items only; ssv_kernels.hip.h, "block tails")
+    if (c->order_tail_blocks && !c->tails_gathered) {
+        hipLaunchKernelGGL(ssv_gather_tails, dim3((c->order_tail_blocks + kGatherBlocks - 1) / kGatherBlocks), dim3(256), 0, after, (const uint64_t*)c->tails,
+                           (const uint32_t*)c->tail_counts, c->order_tail_blocks, c->d_hits, c->d_count, c->hit_capacity);
+        c->tails_gathered = true;
     }
-    const uint32_t nchunks = (nbuckets + kScanChunk - 1) / kScanChunk;
-    // (no fills and no copies around the five kernels: the sorters leave every count they consumed at zero, the last kernel
-    // clears the other set of state words for the next pass and writes this pass's outcome into pinned host memory -- unless
-    // the ordering before this one was never seen to finish: then everything starts from zero)
-    if (c->order_dirty) {
-        HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, c->bucket_alloc * sizeof(uint32_t), stream));
-        HIP_TRY(c->err, hipMemsetAsync(c->order_state, 0, 2 * sizeof(OrderState), stream));
-    }
-    c->order_dirty = true;
-    OrderState* const state = c->order_state + (c->order_parity & 1u);
-    OrderState* const next_state = c->order_state + ((c->order_parity + 1u) & 1u);
-    c->order_parity++;
-    const unsigned pass_blocks = (unsigned)std::min<uint64_t>((count + 1023) / 1024, (uint64_t)c->resident_blocks * 2);     // up to 1024 keys per workgroup and round
-    hipLaunchKernelGGL(ssv_bucket_count, dim3(pass_blocks), dim3(256), 0, stream, (const uint64_t*)d_hits, count, shift, base, c->bucket_counts);
-    hipLaunchKernelGGL(ssv_bucket_scan, dim3(nchunks), dim3(256), 0, stream, c->bucket_counts, nbuckets, c->bucket_offsets, c->bucket_chunk_base,
-                       nchunks, c->bucket_large, state, count);
-    hipLaunchKernelGGL(ssv_bucket_scatter, dim3(pass_blocks), dim3(256), 0, stream, (const uint64_t*)d_hits, count, shift, base,
-                       (const uint64_t*)c->bucket_chunk_base, (const uint32_t*)c->bucket_offsets, c->bucket_counts, c->sort_alt,
-                       (const OrderState*)state);
-    hipLaunchKernelGGL(ssv_bucket_sort_small, dim3(std::min<uint32_t>((nbuckets + 3) / 4, 1u << 24)), dim3(256), 0, stream, (const uint64_t*)c->sort_alt, d_hits,
-                       (const uint64_t*)c->bucket_chunk_base, (const uint32_t*)c->bucket_offsets, c->bucket_counts, nbuckets,
-                       shift, base, row_bits, (const OrderState*)state);
-    hipLaunchKernelGGL(ssv_bucket_sort_large, dim3(128), dim3(256), 0, stream, (const uint64_t*)c->sort_alt, d_hits,
-                       (const uint64_t*)c->bucket_chunk_base, (const uint32_t*)c->bucket_offsets, c->bucket_counts,
-                       (const uint32_t*)c->bucket_large, shift, base, row_bits, (const OrderState*)state, next_state, c->h_order_state);
+    const size_t scan_bytes = (size_t)(kScanChunk + 64u) * sizeof(uint32_t), large_bytes = (size_t)c->large_capacity * sizeof(uint32_t);
+    const int cus = c->resident_blocks / kBlocksPerCu;
+    c->h_report->status = kOrderNone;
+    // Grids: the kernels walk the list in strides of their grid, so any size is right; the count is not known here, the LAST
+    // pass's is (same context, usually the same workload): enough workgroups for a quarter more than that, within bounds --
+    // a grid whose workgroups mostly have nothing to do still costs its dispatch (a 64-row model x 100 Mbp orders 50,000 records).
+    const uint64_t guess = c->last_found ? c->last_found + c->last_found / 4 + 4096 : ~0ull;
+    const dim3 block(kOrderThreads);
+    const dim3 stream_grid((unsigned)std::min<uint64_t>(12 * cus, std::max<uint64_t>(16, guess / 1024)));      // 1024 keys per workgroup and step
+    const dim3 sort_grid((unsigned)std::min<uint64_t>(32 * cus, std::max<uint64_t>(16, guess / (kTargetBucket / 2 * 4))));     // a bucket per wave: every sort is a chain of memory latencies
+    hipLaunchKernelGGL(ssv_order_count, stream_grid, block, 0, after, a);
+    hipLaunchKernelGGL(ssv_order_scan, dim3((unsigned)((a.max_buckets + kScanChunk - 1) / kScanChunk)), block, scan_bytes, after, a);
+    hipLaunchKernelGGL(ssv_order_scatter, stream_grid, block, 0, after, a);
+    // (the large buckets' LDS sorter has a launch of its own: the three kernels that touch every record then fit into what an SSV
+    // kernel leaves free on a SIMD, and only its few workgroups take the ticket that finds the one which reports)
+    hipLaunchKernelGGL(ssv_order_sort, sort_grid, block, 0, after, a);
+    hipLaunchKernelGGL(ssv_order_finish, dim3((unsigned)std::max(1, cus / 2)), block, large_bytes, after, a);
     HIP_TRY(c->err, hipGetLastError());
-    c->bucket_ordered = true;
-    c->last_order_buckets = nbuckets;
+    HIP_TRY(c->err, hipEventRecord(c->ev[3], after));
     return HAVAC_OK;
 }
 
+// finish = begin + end.  Since round 5 a pass is enqueued whole -- preparation, SSV kernel, ordering: three launches, the count
+// never visits the host in between -- so _begin has nothing left to do; the two halves stay for callers that begin several
+// contexts before they end any (havac_dev_wait over the GPUs of a handle).
 extern "C" int havac_ssv_finish_begin(havac_ssv_ctx* c) {
     if (!c) return HAVAC_E_ARGUMENT;
     if (!c->pending) { c->err = "no pass enqueued"; return HAVAC_E_LOGIC; }
-    if (c->ordering) { c->err = "havac_ssv_finish_begin called twice for one pass"; return HAVAC_E_LOGIC; }
-    // (every error return below ends the pass: with `pending` left set a second finish_begin would order a list that is
-    // partly records already, and set_tuning / set_sequence_window would be refused for good; order_dirty stays set, so the
-    // next pass's ordering starts from zeroed counters.  ADVICE round 3)
-    if (hipError_t e = hipSetDevice(c->device); e != hipSuccess) { c->pending = false; c->err = hip_msg("hipSetDevice", e); return HAVAC_E_RUNTIME; }
-    hipError_t waited = hipEventSynchronize(c->ev[4]);
-    if (waited != hipSuccess) { c->pending = false; c->err = hip_msg("hipEventSynchronize", waited); return HAVAC_E_RUNTIME; }
-    const hipStream_t order = c->order_stream ? c->order_stream : c->stream;     // the kernel is done: no device-side dependency needed
-    c->found = *c->h_count;
-    if ((uint32_t)c->h_count[1] != 0) {
-        c->pending = false;
-        (void)hipMemsetAsync(c->tickets + kTicketCounters * kTicketStride, 0, sizeof(uint32_t), c->stream);
-        c->err = "the SSV kernel gave up waiting for a row block of a tile (work-queue fault)";
-        return HAVAC_E_RUNTIME;
-    }
-    const uint64_t stored = c->found < c->hit_capacity ? c->found : c->hit_capacity;
-    int rc = order_records(c, c->d_hits, stored, order);
-    if (rc) { c->pending = false; return rc; }
-    if (hipError_t e = hipEventRecord(c->ev[3], order); e != hipSuccess) { c->pending = false; c->err = hip_msg("hipEventRecord", e); return HAVAC_E_RUNTIME; }
-    c->ordering = true;
     return HAVAC_OK;
 }
 
 extern "C" int havac_ssv_finish_end(havac_ssv_ctx* c, uint64_t* hit_count_out) {
     if (!c) return HAVAC_E_ARGUMENT;
-    if (!c->pending || !c->ordering) { c->err = "no pass is being ordered: call havac_ssv_finish_begin first"; return HAVAC_E_LOGIC; }
-    c->pending = false; c->ordering = false;
+    if (!c->pending) { c->err = "no pass enqueued"; return HAVAC_E_LOGIC; }
+    // (every return below ends the pass)
+    c->pending = false;
     HIP_TRY(c->err, hipSetDevice(c->device));
-    HIP_TRY(c->err, hipEventSynchronize(c->ev[3]));
-    c->last_order_path = c->bucket_ordered ? 1 : 0;
-    if (c->bucket_ordered) {
-        c->order_dirty = false;                // the last kernel of the ordering has run
-        c->last_order_largest = c->h_order_state->largest;
-        if (c->h_order_state->oversized) {
-            // a bucket too big for an LDS sort (or counts left behind by a pass that was cut short): nothing was moved
-            // (hit_order.hip.h) -- this pass takes the generic path, and the counts start from zero again
-            const hipStream_t order = c->order_stream ? c->order_stream : c->stream;
-            HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, c->bucket_alloc * sizeof(uint32_t), order));
-            int rc = order_by_radix_sort(c, c->d_hits, c->order_count, order);
-            if (rc) return rc;
-            HIP_TRY(c->err, hipEventRecord(c->ev[3], order));
-            HIP_TRY(c->err, hipEventSynchronize(c->ev[3]));
-            c->last_order_path = 2;
+    const hipStream_t after = c->order_stream ? c->order_stream : c->stream;
+    const PassReport* const rep = c->h_report;
+    c->last_order_path = 1; c->last_order_buckets = 0; c->last_order_largest = 0;
+    for (int attempt = 0;; attempt++) {
+        if (hipError_t e = hipEventSynchronize(c->ev[3]); e != hipSuccess) { c->order_dirty = true; c->err = hip_msg("hipEventSynchronize", e); return HAVAC_E_RUNTIME; }
+        const uint32_t status = __atomic_load_n(&rep->status, __ATOMIC_ACQUIRE);
+        c->found = rep->found;
+        c->last_order_buckets = rep->nbuckets; c->last_order_largest = rep->largest;
+        if (rep->ssv_fault) {
+            c->order_dirty = true;
+            c->err = "the SSV kernel gave up waiting for a row block of a tile (work-queue fault)";
+            return HAVAC_E_RUNTIME;
         }
+        if (status == kOrderDone || status == kOrderOverflow) { c->last_found = std::min<uint64_t>(c->found, c->hit_capacity); break; }
+        if (status == kOrderRetry && attempt < 4) {
+            // a buffer of the context was too small for this pass; nothing was moved: grow it, clear the barrier words, again
+            if (int rc = ensure_alt(c, rep->need_alt, after)) return rc;
+            if (rep->need_buckets == 0 || rep->need_buckets > c->bucket_alloc) { if (int rc = ensure_buckets(c, std::max<uint32_t>(rep->need_buckets, 1u << 16), after)) return rc; }
+            if (rep->need_large > c->large_capacity) { uint32_t cap = c->large_capacity; while (cap < rep->need_large && cap < kLargeBucket) cap *= 2; c->large_capacity = cap; }
+            HIP_TRY(c->err, hipMemsetAsync(c->control + kControlOrderState, 0, sizeof(OrderState), after));
+            unsigned seg_bits = c->key_bits - 14 - c->row_bits;
+            if (int rc = launch_ordering(c, seg_bits)) return rc;
+            continue;
+        }
+        if (status == kOrderGeneric) {
+            // the generic path: what the blocks left in their tails joins the queue, then radix sort + key -> record
+            c->last_order_path = c->tune_ordering == 0 ? 0 : 2;
+            if (rep->oversized & 2u) HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, c->bucket_alloc * sizeof(uint32_t), after));
+            if (int rc = order_by_radix_sort(c, c->d_hits, c->found, after)) return rc;
+            HIP_TRY(c->err, hipEventRecord(c->ev[3], after));
+            HIP_TRY(c->err, hipEventSynchronize(c->ev[3]));
+            break;
+        }
+        c->order_dirty = true;
+        c->err = "the ordering kernels did not report (status " + std::to_string(status) + ")";
+        return HAVAC_E_RUNTIME;
     }
     HIP_TRY(c->err, hipEventElapsedTime(&c->ssv_ms, c->ev[1], c->ev[2]));
     HIP_TRY(c->err, hipEventElapsedTime(&c->total_ms, c->ev[0], c->ev[3]));

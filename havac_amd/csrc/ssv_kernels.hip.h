@@ -113,6 +113,8 @@ constexpr uint32_t kOutsideCode = 16 * 8;         // byte offset of that entry
 constexpr int kTableBytes = 2304;                 // 16 x 136 = 2176, rounded up to a multiple of 128
 constexpr int kHitStage = 128;                    // records staged per wave (1 KiB)
 constexpr int kTailSlots = 128;                   // records a block may leave in its slots of the side buffer when it ends (block tails)
+constexpr int kTicketStride = 16;                 // the ticket counters and the fault word sit in cache lines of their own
+constexpr int kTicketCounters = 8;                // one per partition of a launch (SsvRare::parts_log2 <= 3)
 
 // sort key of a hit: (segment, row, column-in-segment) -- the FPGA's emission
 // order (device/HavacHls.cpp:151-152,264; device/HitReporting.cpp:178-337)
@@ -157,12 +159,18 @@ __device__ __forceinline__ uint32_t padded_model_row(const uint32_t* __restrict_
 // itself, not from the padded copy: the two halves do not depend on each other), thread 0 clears the hit counter.  As
 // three dispatches (memset, pad, flags) in front of every SSV kernel the preparation cost ~30 us of dispatch gaps per
 // pass -- 1.5 % of a C2 step -- for 10 us of work.
+// Round 5: it also clears everything the pass's kernels count in -- the hit counter, the tickets of cut tiles, the ordering's
+// shared words (`control`, ncontrol words) and the hand-off counts of cut tiles (`handoff`, nhandoff words): no fill is enqueued
+// around the launches of a pass.
 __global__ void ssv_prepare_model(const int8_t* __restrict__ phmm, uint32_t nrows, uint32_t* __restrict__ rows, uint32_t nwords,
                                   uint32_t nrows_padded, uint32_t* __restrict__ flags, uint32_t nflagwords /* 0: no flags */,
-                                  unsigned long long* __restrict__ hit_count) {
+                                  unsigned long long* __restrict__ hit_count, uint32_t* __restrict__ control, uint32_t ncontrol,
+                                  uint32_t* __restrict__ handoff, uint32_t nhandoff) {
     const uint32_t* const phmm_rows = reinterpret_cast<const uint32_t*>(phmm);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *hit_count = 0ull;
+    if (i < ncontrol) control[i] = 0u;
+    for (uint32_t k = i; k < nhandoff; k += gridDim.x * blockDim.x) handoff[k] = 0u;
     if (i < nwords) rows[i] = padded_model_row(phmm_rows, nrows, i);
     if (nflagwords == 0) return;
     // one thread per chunk, 64 chunks = two flag words per wave
@@ -967,8 +975,6 @@ __device__ __forceinline__ uint32_t word_selector(uint32_t a) { return 0x040c000
 // wave with the next row block of that tile picks them up.  See "items" in ssv_diag_body for the order of the items and
 // why a wait for a row block always ends.
 constexpr uint32_t kWholeTile = 0xffffffffu;  // run_item: not a row block, the whole tile
-constexpr int kTicketStride = 16;          // the ticket counter and the fault word sit in cache lines of their own
-constexpr int kTicketCounters = 8;         // one per partition of a launch (SsvRare::parts_log2 <= 3)
 constexpr int kBlocksPerCu = 4 * HAVAC_WAVES_PER_SIMD / kWavesPerBlock;   // 24 waves per CU = 6 waves per SIMD
 constexpr uint32_t kHandoffSpins = 1u << 26;   // x ~1 us: a minute, far beyond any row block (dense-hit models take ~1 s each)
 
