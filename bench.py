@@ -583,27 +583,28 @@ def main():
             torch.cuda.synchronize(device)
 
     def run_steps(engine, nsteps, stage="passes"):
-        """`nsteps` whole passes, all finished on return -> (last result, per-pass (kernel ms, enqueue-to-ordered ms))"""
-        result, timings = None, []
-        for k in range(nsteps):
-            watchdog.stage(f"{stage}: pass {k + 1} of {nsteps}")
-            if die_at and die_at[:2] == (rank, k + 1) and stage == "timed region":      # (tests only)
-                if len(die_at) > 2:
-                    time.sleep(3600)         # a rank that hangs: its own watchdog, and every peer's, must end the job
-                os._exit(17)                 # a rank that dies without a word
-            engine.submit(d_seq, ncols, d_phmm, nrows)
-            if len(engine.in_flight) == len(engine.slots):
-                result = engine.collect()
-                timings.append(engine.ctx.last_ms())
-        while engine.in_flight:
-            result = engine.collect()
-            timings.append(engine.ctx.last_ms())
-        return result, timings
+        """`nsteps` whole passes, all finished on return -> (last result, per-pass (kernel ms, enqueue-to-ordered ms)).  The
+        loop -- submit, and collect the oldest once every slot is in flight -- runs inside libhavac_dev.so (havac_pipe_run): no
+        Python between two passes, the timed region is what a C++ caller of the library gets."""
+        if die_at and stage == "timed region" and die_at[0] == rank:      # (tests only)
+            before = die_at[1] - 1
+            result, timings = engine.run_many(before, d_seq, ncols, d_phmm, nrows, inputs_ready=True) if before > 0 else (None, [])
+            watchdog.stage(f"{stage}: pass {die_at[1]} of {nsteps}")
+            if len(die_at) > 2:
+                time.sleep(3600)         # a rank that hangs: its own watchdog, and every peer's, must end the job
+            os._exit(17)                 # a rank that dies without a word
+        # (the deadline of a stage that holds `nsteps` passes: the per-stage one, and room for the passes themselves)
+        watchdog.stage(f"{stage}: {nsteps} pass(es)", limit_s=(args.deadline + nsteps * pass_seconds * 3) if args.deadline else None)
+        return engine.run_many(nsteps, d_seq, ncols, d_phmm, nrows, inputs_ready=True)
 
     # set-up, not warm-up: one pass through every slot so that each context has its sort buffers before anything is
     # timed (a slot first used inside the timed region would pay a hipMalloc there when --warmup < --pipeline-depth)
     engine_now = engine
+    pass_seconds = 1.0
+    torch.cuda.synchronize(device)          # the inputs are in place: no pass waits for torch's stream from here on
+    t_setup = time.perf_counter()
     run_steps(engine, depth, "set-up")
+    pass_seconds = max(1e-4, (time.perf_counter() - t_setup) / depth)
     # Clock warm-up, independent of --warmup: under this load the GPU reaches its clock only after ~10 launches of 2 ms (the
     # kernel's duration falls from 2.11 to 1.83 ms over the first ten launches of a run).  Untimed passes until the kernel's
     # event time has stopped falling -- three passes in a row within 0.5 % of the best seen -- at most 30 passes or 3 s.

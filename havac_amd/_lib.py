@@ -36,6 +36,10 @@ SIGNATURES = {
     "havac_dev_write_sequence_records": (C.c_int, [_vp, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "havac_dev_append_reverse_strand": (C.c_int, [_vp, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     "havac_dev_run_async": (C.c_int, [_vp]),
+    "havac_dev_set_pipeline_depth": (C.c_int, [_vp, C.c_uint32]),
+    "havac_dev_pipeline_depth": (C.c_uint32, [_vp]),
+    "havac_dev_retire": (C.c_int, [_vp]),
+    "havac_dev_open_runs": (C.c_uint32, [_vp]),
     "havac_dev_state": (C.c_int, [_vp]),
     "havac_dev_wait": (C.c_int, [_vp, C.c_uint32]),
     "havac_dev_abort": (C.c_int, [_vp]),
@@ -70,6 +74,28 @@ SIGNATURES = {
     "havac_ssv_shard_cells": (C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
     "havac_ssv_shard_columns": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32,
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "havac_ssv_set_early_preparation": (C.c_int, [_vp, C.c_int]),
+    "havac_ssv_query": (C.c_int, [_vp]),
+    "havac_ssv_wait_inputs": (C.c_int, [_vp, C.c_int]),
+    "havac_pipe_create": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
+    "havac_pipe_destroy": (None, [_vp]),
+    "havac_pipe_submit": (C.c_int, [_vp, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "havac_pipe_collect": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p]),
+    "havac_pipe_run": (C.c_int, [_vp, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "havac_pipe_poll": (C.c_int, [_vp]),
+    "havac_pipe_wait_inputs": (C.c_int, [_vp, C.c_int]),
+    "havac_pipe_depth": (C.c_uint32, [_vp]),
+    "havac_pipe_in_flight": (C.c_uint32, [_vp]),
+    "havac_pipe_used_two_streams": (C.c_int, [_vp]),
+    "havac_pipe_context": (C.c_void_p, [_vp, C.c_int]),
+    "havac_pipe_set_gather": (C.c_int, [_vp, _vp]),
+    "havac_pipe_wait_gathers": (C.c_int, [_vp]),
+    "havac_pipe_gather_times": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "havac_pipe_last_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "havac_pipe_release": (C.c_int, [_vp]),
+    "havac_pipe_last_error": (C.c_char_p, [_vp]),
+    "havac_gather_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "havac_gather_rccl_version": (C.c_int, [C.POINTER(C.c_int)]),
     "havac_gather_unique_id": (C.c_int, [C.c_void_p]),
     "havac_gather_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -7,5 +7,5 @@ out="$here/.."
 mkdir -p "$here/../../build"
 cd "$here/../../build"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
-    -o "$out/libhavac_dev.so.tmp" "$here/havac_dev.hip" "$here/havac_gather.hip" -ldl "$@"
+    -o "$out/libhavac_dev.so.tmp" "$here/havac_dev.hip" "$here/havac_pipe.hip" "$here/havac_gather.hip" -ldl "$@"
 mv -f "$out/libhavac_dev.so.tmp" "$out/libhavac_dev.so"

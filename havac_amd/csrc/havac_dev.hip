@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <string>
 #include <thread>
@@ -342,7 +343,8 @@ struct havac_ssv_ctx {
     int tune_ordering = -1;                    // -1 / 1: bucket ordering, 0: always the radix sort (experiments, tests)
     uint32_t last_order_buckets = 0, last_order_largest = 0; int last_order_path = 0;   // what the last pass's ordering did (tests, tools)
     unsigned long long* d_count = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // pass start, kernel start, kernel end, records ordered
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pass start, kernel start, kernel end, records ordered, model prepared
+    bool prepare_early = false;                // havac_ssv_set_early_preparation: the pass's first kernel runs on the ordering stream
     CellRecord* trace_cells = nullptr; uint32_t trace_row0 = 0, trace_rows = 0, trace_cols = 0; uint64_t trace_col0 = 0;   // per-cell trace window (debugging)
     hipStream_t order_stream = nullptr;        // optional: where finish() orders the records (default: the enqueue's stream)
     uint64_t window_first = 0, window_columns = 0;   // the caller's sequence buffer holds only these columns (0, 0: all of them)
@@ -455,6 +457,13 @@ extern "C" int havac_ssv_set_order_stream(havac_ssv_ctx* c, void* hip_stream) {
     if (!c) return HAVAC_E_ARGUMENT;
     if (c->pending) { c->err = "a pass is in flight: set the ordering stream between passes"; return HAVAC_E_LOGIC; }
     c->order_stream = (hipStream_t)hip_stream;
+    return HAVAC_OK;
+}
+
+extern "C" int havac_ssv_set_early_preparation(havac_ssv_ctx* c, int on) {
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (c->pending) { c->err = "a pass is in flight: change this between passes"; return HAVAC_E_LOGIC; }
+    c->prepare_early = on != 0;
     return HAVAC_OK;
 }
 
@@ -702,21 +711,29 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         if (int rc2 = ensure_alt(c, std::min<uint64_t>(hit_capacity, 1ull << 22), stream)) return rc2;
         if (int rc2 = ensure_buckets(c, 1u << 16, stream)) return rc2;
     }
+    // The pass's first kernel (the padded model, the chunk flags, the cleared counters) normally runs in front of the SSV kernel, on
+    // its stream.  Where passes run beside each other it may run EARLY instead, on this context's ordering stream, which is idle
+    // when a pass is enqueued: the kernel stream then holds nothing but SSV kernels, back to back -- one dependent launch
+    // between two of them instead of two and a 4 us kernel (havac_ssv_set_early_preparation; the caller has made the ordering
+    // stream wait for the inputs).
+    const hipStream_t prep = (c->prepare_early && c->order_stream) ? c->order_stream : stream;
     if (c->order_dirty && c->bucket_counts) {     // an earlier ordering was cut short: its counts cannot be trusted
-        HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, c->bucket_alloc * sizeof(uint32_t), stream));
+        HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, c->bucket_alloc * sizeof(uint32_t), prep));
         c->order_dirty = false;
     }
 
-    HIP_TRY(c->err, hipEventRecord(c->ev[0], stream));
+    HIP_TRY(c->err, hipEventRecord(c->ev[0], prep));
     // one launch: the padded copy of the model, the chunk flags, and everything the pass's kernels count in, cleared -- the hit
     // counter, the tickets, the tails' sums, the ordering's barrier words, the hand-off counts of cut tiles.  (Separator pairs
     // score -128 twice in a row whatever the model says: with a mask there are no flags, every chunk tests every two steps.)
     {
         const uint32_t nflagwords = c->pair_mask ? 0u : flag_words;
         const uint32_t threads = std::max(std::max(model_words, nflagwords * 32u), kControlWords);
-        hipLaunchKernelGGL(ssv_prepare_model, dim3((threads + 255) / 256), dim3(256), 0, stream, d_phmm, nrows, c->rows8, model_words,
+        hipLaunchKernelGGL(ssv_prepare_model, dim3((threads + 255) / 256), dim3(256), 0, prep, d_phmm, nrows, c->rows8, model_words,
                            t.nrows_padded, c->chunk_flags, nflagwords, c->d_count, c->control, kControlWords, c->block_flags, (uint32_t)handoff_words);
     }
+    HIP_TRY(c->err, hipEventRecord(c->ev[4], prep));
+    if (prep != stream) HIP_TRY(c->err, hipStreamWaitEvent(stream, c->ev[4], 0));
     HIP_TRY(c->err, hipEventRecord(c->ev[1], stream));
     if (te > tb) {
         SsvRare& R = L;
@@ -941,6 +958,24 @@ extern "C" int havac_ssv_finish(havac_ssv_ctx* c, uint64_t* hit_count_out) {
     return havac_ssv_finish_end(c, hit_count_out);
 }
 
+extern "C" int havac_ssv_query(havac_ssv_ctx* c) {
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (!c->pending) { c->err = "no pass enqueued"; return HAVAC_E_LOGIC; }
+    const hipError_t q = hipEventQuery(c->ev[3]);
+    if (q == hipSuccess) return 1;
+    if (q == hipErrorNotReady) return 0;
+    c->err = hip_msg("hipEventQuery", q);
+    return HAVAC_E_RUNTIME;
+}
+
+extern "C" int havac_ssv_wait_inputs(havac_ssv_ctx* c, int sequence_too) {
+    if (!c) return HAVAC_E_ARGUMENT;
+    if (!c->pending) return HAVAC_OK;                      // nothing enqueued reads anything
+    HIP_TRY(c->err, hipSetDevice(c->device));
+    HIP_TRY(c->err, hipEventSynchronize(c->ev[sequence_too ? 2 : 4]));
+    return HAVAC_OK;
+}
+
 extern "C" int havac_ssv_sort_hits(havac_ssv_ctx* c, uint64_t* d_hits, uint64_t count, void* hip_stream) {
     if (!c || (!d_hits && count)) return HAVAC_E_ARGUMENT;
     if (count == 0) return HAVAC_OK;
@@ -1010,44 +1045,76 @@ extern "C" int havac_ssv_last_ms(havac_ssv_ctx* c, float* ssv_kernel_ms, float* 
 // GPUs' ordered hit lists concatenated in shard order are the ordered whole.
 struct DevicePart {
     int device = 0;
-    hipStream_t stream = nullptr;
-    havac_ssv_ctx* ctx = nullptr;
+    hipStream_t stream = nullptr;       // uploads, packing kernels; a run starts behind what this stream holds
+    havac_pipe* pipe = nullptr;         // the runs of this GPU: `depth` slots (context, hit buffer, ordering stream each; havac_pipe.hip)
     uint8_t* d_seq = nullptr; uint64_t seq_alloc = 0;
     int8_t* d_phmm = nullptr; uint64_t phmm_alloc = 0;
     uint8_t* d_mask = nullptr; uint64_t mask_alloc = 0;   // separator bitmap, optional
     uint64_t win_first = 0, win_columns = 0;              // d_seq / d_mask hold these columns only (0, 0: all); see upload_columns
-    uint64_t* d_hits = nullptr;
-    uint32_t* d_abort = nullptr;        // device word the kernel polls (cache-bypassing loads)
-    hipStream_t abort_stream = nullptr; // abort() writes the word from here while the kernel runs
-    hipEvent_t done = nullptr;
-    uint64_t found = 0;
+    uint32_t* d_abort = nullptr;        // kMaxDepth device words the kernels poll (cache-bypassing loads), one per run in flight
+    hipStream_t abort_stream = nullptr; // abort() writes the words from here while the kernels run
     // text staging of havac_dev_write_sequence_chars (allocated on first use)
     char* d_chars[2] = {nullptr, nullptr};
     hipEvent_t chars_copied[2] = {nullptr, nullptr}, chars_packed[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
 };
 
+// One run of the handle: havac_dev_run_async opens it, havac_dev_wait / _state / _abort finish it, havac_dev_num_hits / _read_hits
+// read it, the next havac_dev_run_async (depth 1) or havac_dev_retire closes it.
+struct Run {
+    uint32_t abort_word = 0;            // which of the parts' abort words this run polls
+    bool abort_requested = false, finished = false, aborted = false, failed = false, overflowed = false;
+    uint64_t found = 0;                 // all GPUs
+    std::vector<uint64_t> part_found;
+    std::vector<const uint64_t*> part_records;     // each GPU's ordered list (device memory of its pipe's slot)
+    float ssv_ms = 0.f, total_ms = 0.f;
+    std::string err;
+};
+
+constexpr uint32_t kMaxDepth = 4;
 struct havac_dev {
     std::vector<DevicePart> parts;
     uint64_t seq_bytes = 0, phmm_bytes = 0, mask_bytes = 0;
-    uint64_t hit_capacity = 0;          // per GPU
-    bool abort_requested = false;
-    bool has_run = false, finished = false, aborted = false, failed = false, overflowed = false;
-    uint64_t found = 0;                 // all GPUs
+    uint64_t hit_capacity = 0;          // per GPU and run in flight
+    uint32_t depth = 1;                 // runs in flight (havac_dev_set_pipeline_depth); 1 = the reference's one at a time
+    int tuning[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+    std::deque<Run> runs;               // open runs, oldest first: the entry points below speak of the OLDEST
+    bool has_run = false;               // a run was started at some time (the reference's "run object was not initialized")
+    uint64_t submitted = 0;
     std::string err;
 };
 
 // the reference's fixed hit buffer: 14 * 256 MiB = 3.5 GiB = 469,762,048 records (host/HavacHwClient.hpp:94)
 static const uint64_t kDefaultHitCapacity = 14ull * 256ull * 1024ull * 1024ull / sizeof(uint64_t);
 
-static int dev_alloc_hits(havac_dev* d, uint64_t cap) {
+static bool any_unfinished(const havac_dev* d) {
+    for (const Run& r : d->runs) if (!r.finished) return true;
+    return false;
+}
+
+static int apply_tuning(havac_dev* d) {
+    const int* v = d->tuning;
+    for (DevicePart& p : d->parts)
+        for (uint32_t k = 0; k < d->depth; k++) {
+            havac_ssv_ctx* const ctx = havac_pipe_context(p.pipe, (int)k);
+            if (int rc = havac_ssv_set_tuning(ctx, v[0], v[1], v[2], v[3])) { d->err = havac_ssv_ctx_last_error(ctx); return rc; }
+            if (int rc = havac_ssv_set_split_tuning(ctx, v[4], v[5], v[6], v[7])) { d->err = havac_ssv_ctx_last_error(ctx); return rc; }
+            if (int rc = havac_ssv_set_kernel_variant(ctx, v[8])) { d->err = havac_ssv_ctx_last_error(ctx); return rc; }
+        }
+    return HAVAC_OK;
+}
+
+// (re)makes every GPU's pipe: `depth` slots with a hit buffer of `cap` records each.  Finished runs' lists go with the old pipes.
+static int dev_make_pipes(havac_dev* d, uint32_t depth, uint64_t cap) {
+    d->runs.clear();
     for (DevicePart& p : d->parts) {
         HIP_TRY(d->err, hipSetDevice(p.device));
-        if (p.d_hits) { (void)hipFree(p.d_hits); p.d_hits = nullptr; }
-        HIP_TRY(d->err, hipMalloc(&p.d_hits, cap * sizeof(uint64_t)));
+        if (p.pipe) { havac_pipe_destroy(p.pipe); p.pipe = nullptr; }
+        // depth 1: one run at a time, the ordering on the kernel's stream (the reference's behaviour); deeper: the library's rule
+        if (int rc = havac_pipe_create(depth, cap, -1, &p.pipe)) { d->err = "could not allocate the hit buffers and contexts of " + std::to_string(depth) + " run(s) in flight"; return rc; }
     }
-    d->hit_capacity = cap;
-    return HAVAC_OK;
+    d->depth = depth; d->hit_capacity = cap;
+    return apply_tuning(d);
 }
 
 extern "C" int havac_dev_create_multi(const uint32_t* device_indices, uint32_t ndevices, havac_dev** out) {
@@ -1069,13 +1136,11 @@ extern "C" int havac_dev_create_multi(const uint32_t* device_indices, uint32_t n
         if (hipGetDeviceProperties(&prop, p.device) != hipSuccess) return fail(HAVAC_E_NO_DEVICE);
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(HAVAC_E_NO_DEVICE);   // the code object is gfx950 only
         if (hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) != hipSuccess) return fail(HAVAC_E_RUNTIME);
-        if (havac_ssv_ctx_create(&p.ctx) != HAVAC_OK) return fail(HAVAC_E_RUNTIME);
         if (hipStreamCreateWithFlags(&p.abort_stream, hipStreamNonBlocking) != hipSuccess) return fail(HAVAC_E_RUNTIME);
-        if (hipMalloc(&p.d_abort, sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_NOMEM);
-        if (hipMemset(p.d_abort, 0, sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_RUNTIME);
-        if (hipEventCreateWithFlags(&p.done, hipEventDisableTiming) != hipSuccess) return fail(HAVAC_E_RUNTIME);
+        if (hipMalloc(&p.d_abort, kMaxDepth * sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_NOMEM);
+        if (hipMemset(p.d_abort, 0, kMaxDepth * sizeof(uint32_t)) != hipSuccess) return fail(HAVAC_E_RUNTIME);
     }
-    if (dev_alloc_hits(d, kDefaultHitCapacity) != HAVAC_OK) return fail(HAVAC_E_NOMEM);
+    if (dev_make_pipes(d, 1, kDefaultHitCapacity) != HAVAC_OK) return fail(HAVAC_E_NOMEM);
     *out = d;
     return HAVAC_OK;
 }
@@ -1089,11 +1154,10 @@ extern "C" void havac_dev_destroy(havac_dev* d) {
     for (DevicePart& p : d->parts) {
         (void)hipSetDevice(p.device);
         if (p.stream) (void)hipStreamSynchronize(p.stream);
-        if (p.ctx) havac_ssv_ctx_destroy(p.ctx);
+        if (p.pipe) havac_pipe_destroy(p.pipe);
         if (p.d_seq) (void)hipFree(p.d_seq);
         if (p.d_phmm) (void)hipFree(p.d_phmm);
         if (p.d_mask) (void)hipFree(p.d_mask);
-        if (p.d_hits) (void)hipFree(p.d_hits);
         if (p.d_abort) (void)hipFree(p.d_abort);
         for (int k = 0; k < 2; k++) {
             if (p.d_chars[k]) (void)hipFree(p.d_chars[k]);
@@ -1102,7 +1166,6 @@ extern "C" void havac_dev_destroy(havac_dev* d) {
         }
         if (p.copy_stream) (void)hipStreamDestroy(p.copy_stream);
         if (p.abort_stream) (void)hipStreamDestroy(p.abort_stream);
-        if (p.done) (void)hipEventDestroy(p.done);
         if (p.stream) (void)hipStreamDestroy(p.stream);
     }
     delete d;
@@ -1114,13 +1177,22 @@ extern "C" uint32_t havac_dev_device_count(havac_dev* d) { return d ? (uint32_t)
 
 extern "C" int havac_dev_set_hit_capacity(havac_dev* d, uint64_t max_hits) {
     if (!d || max_hits == 0) return HAVAC_E_ARGUMENT;
-    if (d->has_run && !d->finished) { d->err = "cannot resize the hit buffer during a run"; return HAVAC_E_LOGIC; }
-    return dev_alloc_hits(d, max_hits);
+    if (any_unfinished(d)) { d->err = "cannot resize the hit buffer during a run"; return HAVAC_E_LOGIC; }
+    return dev_make_pipes(d, d->depth, max_hits);
 }
+
+extern "C" int havac_dev_set_pipeline_depth(havac_dev* d, uint32_t depth) {
+    if (!d || depth == 0 || depth > kMaxDepth) return HAVAC_E_ARGUMENT;
+    if (any_unfinished(d)) { d->err = "cannot change the number of runs in flight during a run"; return HAVAC_E_LOGIC; }
+    if (depth == d->depth) return HAVAC_OK;
+    return dev_make_pipes(d, depth, d->hit_capacity);
+}
+
+extern "C" uint32_t havac_dev_pipeline_depth(havac_dev* d) { return d ? d->depth : 0; }
 
 extern "C" int havac_dev_set_tuning(havac_dev* d, const int32_t* values, uint32_t count) {
     if (!d || (!values && count)) return HAVAC_E_ARGUMENT;
-    if (d->has_run && !d->finished) { d->err = "cannot change the tuning during a run"; return HAVAC_E_LOGIC; }
+    if (any_unfinished(d)) { d->err = "cannot change the tuning during a run"; return HAVAC_E_LOGIC; }
     int v[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
     for (uint32_t i = 0; i < count && i < 9; i++) v[i] = values[i];
     // everything is checked before anything is applied (the same tests the three setters make): a refused value leaves no GPU half tuned
@@ -1128,10 +1200,18 @@ extern "C" int havac_dev_set_tuning(havac_dev* d, const int32_t* values, uint32_
         d->err = "bad tuning value";
         return HAVAC_E_ARGUMENT;
     }
+    for (int i = 0; i < 9; i++) d->tuning[i] = v[i];
+    return apply_tuning(d);
+}
+
+// Inputs may be rewritten while runs are in flight (depth > 1: the caller loads the next model while the last run still orders
+// its records): the write waits until every run in flight has READ what is about to be overwritten -- the model is read by a
+// pass's first kernel, the sequence by its SSV kernel -- not until the runs have finished.
+static int wait_inputs_read(havac_dev* d, bool sequence_too) {
+    if (!any_unfinished(d)) return HAVAC_OK;
     for (DevicePart& p : d->parts) {
-        if (int rc = havac_ssv_set_tuning(p.ctx, v[0], v[1], v[2], v[3])) { d->err = havac_ssv_ctx_last_error(p.ctx); return rc; }
-        if (int rc = havac_ssv_set_split_tuning(p.ctx, v[4], v[5], v[6], v[7])) { d->err = havac_ssv_ctx_last_error(p.ctx); return rc; }
-        if (int rc = havac_ssv_set_kernel_variant(p.ctx, v[8])) { d->err = havac_ssv_ctx_last_error(p.ctx); return rc; }
+        HIP_TRY(d->err, hipSetDevice(p.device));
+        if (int rc = havac_pipe_wait_inputs(p.pipe, sequence_too ? 1 : 0)) { d->err = havac_pipe_last_error(p.pipe); return rc; }
     }
     return HAVAC_OK;
 }
@@ -1231,6 +1311,7 @@ extern "C" int havac_dev_write_sequence(havac_dev* d, const uint8_t* packed, uin
         d->err = "compressed sequence size must be less than 4GiB. length requested: " + std::to_string(nbytes) + " bytes.";
         return HAVAC_E_LENGTH;
     }
+    if (int rc = wait_inputs_read(d, true)) return rc;
     d->seq_bytes = nbytes;
     d->mask_bytes = 0;                       // a new sequence has no separators until a mask is written for it
     if (nbytes == 0) return HAVAC_OK;
@@ -1256,6 +1337,7 @@ extern "C" int havac_dev_write_sequence_chars(havac_dev* d, const char* chars, u
             d->err = "patch columns must be ascending and inside the padded sequence";
             return HAVAC_E_ARGUMENT;
         }
+    if (int rc = wait_inputs_read(d, true)) return rc;
     d->seq_bytes = nbytes;
     d->mask_bytes = 0;
     whole_copies(d);
@@ -1394,6 +1476,7 @@ extern "C" int havac_dev_write_sequence_records(havac_dev* d, const char* chars,
         d->err = "compressed sequence size must be less than 4GiB. length requested: " + std::to_string(nbytes) + " bytes.";
         return HAVAC_E_LENGTH;
     }
+    if (int rc = wait_inputs_read(d, true)) return rc;
     d->seq_bytes = nbytes;
     d->mask_bytes = 0;
     whole_copies(d);
@@ -1444,7 +1527,7 @@ extern "C" int havac_dev_append_reverse_strand(havac_dev* d, const uint64_t* sta
                                                uint64_t* forward_columns_out) {
     if (!d || (nrecords && (!starts || !residues))) return HAVAC_E_ARGUMENT;
     if (d->seq_bytes == 0) { d->err = "no sequence on the device to append a second strand to"; return HAVAC_E_LOGIC; }
-    if (d->has_run && !d->finished) { d->err = "cannot change the sequence during a run"; return HAVAC_E_LOGIC; }
+    if (int rc = wait_inputs_read(d, true)) return rc;
     if (d->parts[0].win_columns) {
         d->err = "the GPUs of this handle hold column windows of a host-packed sequence (havac_dev_write_sequence): append the "
                  "second strand on the host, or send the text (havac_dev_write_sequence_chars / _records)";
@@ -1503,6 +1586,7 @@ extern "C" int havac_dev_append_reverse_strand(havac_dev* d, const uint64_t* sta
 
 extern "C" int havac_dev_write_separator_mask(havac_dev* d, const uint8_t* pair_bitmap, uint64_t nbytes) {
     if (!d || (!pair_bitmap && nbytes)) return HAVAC_E_ARGUMENT;
+    if (int rc = wait_inputs_read(d, true)) return rc;
     if (nbytes == 0) { d->mask_bytes = 0; return HAVAC_OK; }
     if (nbytes != d->seq_bytes / 4) {        // one bit per symbol pair = 1/8 bit per packed bit
         d->err = "separator mask must hold one bit per symbol pair of the sequence written before it (" +
@@ -1528,114 +1612,141 @@ extern "C" int havac_dev_write_phmm(havac_dev* d, const int8_t* scores, uint64_t
                  std::to_string(nbytes) + " bytes.";
         return HAVAC_E_LENGTH;
     }
+    if (int rc = wait_inputs_read(d, false)) return rc;
     d->phmm_bytes = nbytes;
     if (nbytes == 0) return HAVAC_OK;
     return upload(d, &DevicePart::d_phmm, &DevicePart::phmm_alloc, scores, nbytes);
 }
 
+// ---- runs ----------------------------------------------------------------------------------------------------------------
+// Up to `depth` runs are open at a time (havac_dev_set_pipeline_depth; 1 = the reference's one at a time).  Every entry point
+// below speaks of the OLDEST open run; havac_dev_run_async opens a new one -- at depth 1 a finished run is closed by the next
+// run_async, as the reference's run object is overwritten by the next invokeHavacSsvAsync (host/HavacHwClient.cpp:149); with
+// more runs in flight havac_dev_retire closes the oldest and makes the next one current.
+static Run* first_unfinished(havac_dev* d);
+static int dev_finish(havac_dev* d, Run& r);
 extern "C" int havac_dev_run_async(havac_dev* d) {
     if (!d) return HAVAC_E_ARGUMENT;
     // host/HavacHwClient.cpp:142-147
     if (d->seq_bytes == 0) { d->err = "sequence length in segments cannot be 0, but 0 was given to the client."; return HAVAC_E_LENGTH; }
     if (d->phmm_bytes == 0) { d->err = "phmm length in vectors cannot be 0, but 0 was given to the client."; return HAVAC_E_LENGTH; }
-    if (d->has_run && !d->finished) { d->err = "a run is already in flight"; return HAVAC_E_LOGIC; }
+    if (d->runs.size() == d->depth) {
+        if (!d->runs.front().finished) { d->err = d->depth == 1 ? "a run is already in flight" : "every run slot is in flight: wait for the oldest run and retire it (havac_dev_retire)"; return HAVAC_E_LOGIC; }
+        d->runs.pop_front();            // a finished run makes room (its list goes with it)
+    }
     const uint32_t nparts = (uint32_t)d->parts.size();
     if (d->seq_bytes * 4 / HAVAC_SEGMENT_COLUMNS < nparts) {
         d->err = "the sequence has fewer 12288-column segments than the handle has GPUs";
         return HAVAC_E_LENGTH;
     }
-    d->abort_requested = false;
-    d->aborted = false; d->failed = false; d->finished = false; d->overflowed = false; d->found = 0;
+    Run run;
+    run.abort_word = (uint32_t)(d->submitted % kMaxDepth);
+    run.part_found.assign(nparts, 0); run.part_records.assign(nparts, nullptr);
     for (uint32_t i = 0; i < nparts; i++) {
         DevicePart& p = d->parts[i];
         HIP_TRY(d->err, hipSetDevice(p.device));
-        HIP_TRY(d->err, hipMemsetAsync(p.d_abort, 0, sizeof(uint32_t), p.stream));
-        havac_ssv_set_separator_mask(p.ctx, d->mask_bytes ? p.d_mask : nullptr);
-        havac_ssv_set_sequence_window(p.ctx, p.win_first, p.win_columns);
-        int rc = havac_ssv_enqueue(p.ctx, p.d_seq, d->seq_bytes * 4, p.d_phmm, (uint32_t)(d->phmm_bytes / 4), i, nparts,
-                                   p.d_hits, d->hit_capacity, p.d_abort, p.stream);
+        havac_ssv_ctx* const ctx = havac_pipe_context(p.pipe, -2);          // the slot this run will take
+        havac_ssv_set_separator_mask(ctx, d->mask_bytes ? p.d_mask : nullptr);
+        havac_ssv_set_sequence_window(ctx, p.win_first, p.win_columns);
+        // (nothing to wait for: every write_* entry point returns with its upload complete; and the abort words are zero -- the run
+        // that was aborted last put its own back, see dev_finish -- so a run costs no fill and no event in front of its first kernel)
+        int rc = havac_pipe_submit(p.pipe, p.d_seq, d->seq_bytes * 4, p.d_phmm, (uint32_t)(d->phmm_bytes / 4), i, nparts,
+                                   p.d_abort + run.abort_word, HAVAC_NO_STREAM);
         if (rc) {
-            d->err = havac_ssv_ctx_last_error(p.ctx);
-            for (uint32_t j = 0; j < i; j++) {            // take back what the earlier GPUs were given
-                (void)hipSetDevice(d->parts[j].device);
-                (void)havac_ssv_finish(d->parts[j].ctx, nullptr);
+            d->err = havac_pipe_last_error(p.pipe);
+            // take back what the earlier GPUs were given: they are the newest pass of their pipes; every older open run is finished
+            // first, so that the pipes stay in step (a refused submit is rare: an argument error, or out of memory)
+            if (i > 0) {
+                while (Run* older = first_unfinished(d)) (void)dev_finish(d, *older);
+                for (uint32_t j = 0; j < i; j++) {
+                    (void)hipSetDevice(d->parts[j].device);
+                    (void)havac_pipe_collect(d->parts[j].pipe, nullptr, nullptr, nullptr, d->parts[j].stream);
+                }
             }
             return rc;
         }
-        HIP_TRY(d->err, hipEventRecord(p.done, p.stream));
     }
+    d->runs.push_back(std::move(run));
+    d->submitted++;
     d->has_run = true;
     return HAVAC_OK;
 }
 
-static int final_state(const havac_dev* d) {
-    return d->failed ? HAVAC_STATE_ERROR : (d->aborted ? HAVAC_STATE_ABORT : HAVAC_STATE_COMPLETED);
+static int final_state(const Run& r) {
+    return r.failed ? HAVAC_STATE_ERROR : (r.aborted ? HAVAC_STATE_ABORT : HAVAC_STATE_COMPLETED);
 }
 
-// completes a drained run: every GPU orders its own hits -- all orderings are enqueued before any is waited for, so
-// with several GPUs behind the handle they run side by side
-static int dev_finish(havac_dev* d) {
-    if (d->finished) return final_state(d);
-    d->finished = true;
-    d->found = 0;
-    std::vector<int> begun(d->parts.size(), HAVAC_OK);
-    for (size_t i = 0; i < d->parts.size(); i++) begun[i] = havac_ssv_finish_begin(d->parts[i].ctx);
+// the first open run that has not been finished yet (runs finish in order: a pipe completes its oldest pass first)
+static Run* first_unfinished(havac_dev* d) {
+    for (Run& r : d->runs) if (!r.finished) return &r;
+    return nullptr;
+}
+
+// completes run r, the oldest UNFINISHED one: every GPU's pass is collected (all of it was enqueued at run_async, the ordering
+// included, so the GPUs have been working side by side; the waits here are one after the other and cost nothing extra)
+static int dev_finish(havac_dev* d, Run& r) {
+    if (r.finished) return final_state(r);
+    r.finished = true;
+    r.found = 0;
     for (size_t i = 0; i < d->parts.size(); i++) {
         DevicePart& p = d->parts[i];
-        uint64_t found = 0;
-        const int rc = begun[i] != HAVAC_OK ? begun[i] : havac_ssv_finish_end(p.ctx, &found);
-        p.found = found;
-        d->found += found;
+        (void)hipSetDevice(p.device);
+        uint64_t found = 0, n = 0;
+        const uint64_t* records = nullptr;
+        const int rc = havac_pipe_collect(p.pipe, &found, &records, &n, p.stream);
+        r.part_found[i] = found; r.part_records[i] = records;
+        r.found += found;
+        float a = 0.f, b = 0.f;
+        if (havac_pipe_last_ms(p.pipe, &a, &b) == HAVAC_OK) { r.ssv_ms = std::max(r.ssv_ms, a); r.total_ms = std::max(r.total_ms, b); }      // the slowest GPU
         if (rc != HAVAC_OK) {
-            d->err = havac_ssv_ctx_last_error(p.ctx);
-            d->failed = true;
-            if (rc == HAVAC_E_HIT_OVERFLOW) d->overflowed = true;
+            r.err = havac_pipe_last_error(p.pipe);
+            d->err = r.err;
+            r.failed = true;
+            if (rc == HAVAC_E_HIT_OVERFLOW) r.overflowed = true;
+        }
+        if (r.abort_requested) {      // the word this run was stopped through is put back for the runs to come
+            (void)hipMemsetAsync(p.d_abort + r.abort_word, 0, sizeof(uint32_t), p.abort_stream);
+            (void)hipStreamSynchronize(p.abort_stream);
         }
     }
-    d->aborted = d->abort_requested;
-    return final_state(d);
+    r.aborted = r.abort_requested;
+    return final_state(r);
 }
 
-// hipSuccess when every GPU's work has drained, hipErrorNotReady while any has not
-static hipError_t query_all(havac_dev* d) {
+// 1 when every GPU's pass of the oldest unfinished run has drained, 0 while any has not, negative on error
+static int query_all(havac_dev* d) {
     for (DevicePart& p : d->parts) {
-        hipError_t q = hipEventQuery(p.done);
-        if (q != hipSuccess) return q;
+        const int q = havac_pipe_poll(p.pipe);
+        if (q <= 0) { if (q < 0) d->err = havac_pipe_last_error(p.pipe); return q; }
     }
-    return hipSuccess;
+    return 1;
 }
 
 extern "C" int havac_dev_state(havac_dev* d) {
     if (!d) return HAVAC_E_ARGUMENT;
-    if (!d->has_run) {   // host/HavacHwClient.cpp:168
+    if (!d->has_run || d->runs.empty()) {   // host/HavacHwClient.cpp:168
         d->err = "run object was not initialized. run function invokeHavacSsvAsync to initialize this object.";
         return HAVAC_E_LOGIC;
     }
-    if (d->finished) return final_state(d);
-    hipError_t q = query_all(d);
-    if (q == hipErrorNotReady) return HAVAC_STATE_RUNNING;
-    if (q != hipSuccess) { d->err = hip_msg("hipEventQuery", q); return HAVAC_STATE_ERROR; }
-    return dev_finish(d);
-}
-
-static int sync_all(havac_dev* d) {
-    for (DevicePart& p : d->parts) {
-        hipError_t e = hipEventSynchronize(p.done);
-        if (e != hipSuccess) { d->err = hip_msg("hipEventSynchronize", e); d->finished = true; d->failed = true; return HAVAC_STATE_ERROR; }
-    }
-    return dev_finish(d);
+    Run& cur = d->runs.front();
+    if (cur.finished) return final_state(cur);
+    const int q = query_all(d);
+    if (q == 0) return HAVAC_STATE_RUNNING;
+    if (q < 0) return HAVAC_STATE_ERROR;
+    return dev_finish(d, cur);
 }
 
 extern "C" int havac_dev_wait(havac_dev* d, uint32_t timeout_ms) {
     if (!d) return HAVAC_E_ARGUMENT;
-    if (!d->has_run) { d->err = "no run to wait for"; return HAVAC_E_LOGIC; }
-    if (d->finished) return havac_dev_state(d);
-    if (timeout_ms == 0) return sync_all(d);
+    if (!d->has_run || d->runs.empty()) { d->err = "no run to wait for"; return HAVAC_E_LOGIC; }
+    Run& cur = d->runs.front();
+    if (cur.finished) return final_state(cur);
+    if (timeout_ms == 0) return dev_finish(d, cur);
     auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms);
     for (;;) {
-        hipError_t q = query_all(d);
-        if (q == hipSuccess) return dev_finish(d);
-        if (q != hipErrorNotReady) { d->err = hip_msg("hipEventQuery", q); d->finished = true; d->failed = true; return HAVAC_STATE_ERROR; }
+        const int q = query_all(d);
+        if (q > 0) return dev_finish(d, cur);
+        if (q < 0) { cur.finished = true; cur.failed = true; return HAVAC_STATE_ERROR; }
         if (std::chrono::steady_clock::now() >= deadline) return HAVAC_STATE_TIMEOUT;
         std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
@@ -1643,30 +1754,46 @@ extern "C" int havac_dev_wait(havac_dev* d, uint32_t timeout_ms) {
 
 extern "C" int havac_dev_abort(havac_dev* d) {
     if (!d) return HAVAC_E_ARGUMENT;
-    if (!d->has_run) { d->err = "no run to abort"; return HAVAC_E_LOGIC; }
-    if (d->finished) return havac_dev_state(d);
-    if (query_all(d) == hipSuccess) return dev_finish(d);
+    if (!d->has_run || d->runs.empty()) { d->err = "no run to abort"; return HAVAC_E_LOGIC; }
+    Run& cur = d->runs.front();
+    if (cur.finished) return final_state(cur);
+    if (query_all(d) > 0) return dev_finish(d, cur);
+    // every run in flight is stopped: the oldest is finished here, the others report ABORT when their turn comes
     static const uint32_t one = 1;
-    d->abort_requested = true;
-    for (DevicePart& p : d->parts) {
-        hipError_t e = hipSetDevice(p.device);
-        if (e == hipSuccess) e = hipMemcpyAsync(p.d_abort, &one, sizeof one, hipMemcpyHostToDevice, p.abort_stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(p.abort_stream);
-        if (e != hipSuccess) { d->err = hip_msg("abort", e); d->finished = true; d->failed = true; return HAVAC_STATE_ERROR; }
+    for (Run& r : d->runs) {
+        if (r.finished) continue;
+        r.abort_requested = true;
+        for (DevicePart& p : d->parts) {
+            hipError_t e = hipSetDevice(p.device);
+            if (e == hipSuccess) e = hipMemcpyAsync(p.d_abort + r.abort_word, &one, sizeof one, hipMemcpyHostToDevice, p.abort_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(p.abort_stream);
+            if (e != hipSuccess) { d->err = hip_msg("abort", e); cur.finished = true; cur.failed = true; return HAVAC_STATE_ERROR; }
+        }
     }
-    return sync_all(d);
+    return dev_finish(d, cur);
 }
+
+extern "C" int havac_dev_retire(havac_dev* d) {
+    if (!d) return HAVAC_E_ARGUMENT;
+    if (d->runs.empty()) { d->err = "no open run to retire"; return HAVAC_E_LOGIC; }
+    if (!d->runs.front().finished) { const int s = havac_dev_wait(d, 0); if (s < 0) return s; }
+    d->runs.pop_front();
+    return HAVAC_OK;
+}
+
+extern "C" uint32_t havac_dev_open_runs(havac_dev* d) { return d ? (uint32_t)d->runs.size() : 0; }
 
 extern "C" int havac_dev_num_hits64(havac_dev* d, uint64_t* count) {
     if (!d || !count) return HAVAC_E_ARGUMENT;
-    if (!d->has_run) { d->err = "num hits was not set by the client!"; return HAVAC_E_RUNTIME; }   // HavacHwClient.cpp:181-183
-    if (!d->finished) { int s = havac_dev_wait(d, 0); if (s < 0) return s; }
-    if (d->failed) return d->overflowed ? HAVAC_E_HIT_OVERFLOW : HAVAC_E_RUNTIME;
-    if (d->aborted) {       // the sweep stopped part-way: whatever it had queued is not a hit list
+    if (!d->has_run || d->runs.empty()) { d->err = "num hits was not set by the client!"; return HAVAC_E_RUNTIME; }   // HavacHwClient.cpp:181-183
+    Run& cur = d->runs.front();
+    if (!cur.finished) { int s = havac_dev_wait(d, 0); if (s < 0) return s; }
+    if (cur.failed) { d->err = cur.err; return cur.overflowed ? HAVAC_E_HIT_OVERFLOW : HAVAC_E_RUNTIME; }
+    if (cur.aborted) {       // the sweep stopped part-way: whatever it had queued is not a hit list
         d->err = "the run was aborted: it has no hit list";
         return HAVAC_E_LOGIC;
     }
-    *count = d->found;
+    *count = cur.found;
     return HAVAC_OK;
 }
 
@@ -1689,22 +1816,25 @@ extern "C" int havac_dev_read_hits64(havac_dev* d, uint64_t* out, uint64_t n) {
     int rc = havac_dev_num_hits64(d, &have);
     if (rc) return rc;
     if (n > have) n = have;
+    const Run& cur = d->runs.front();
     // shard order is device order: the GPUs' lists are simply laid end to end -- every GPU's copy is enqueued before any is
-    // waited for, so with several GPUs behind the handle the copies cross PCIe side by side
+    // waited for, so with several GPUs behind the handle the copies cross PCIe side by side.  (On the GPU's abort stream: the
+    // handle's own stream may already hold the next run's uploads, and the list is complete -- the run was waited for.)
     uint64_t at = 0;
     std::vector<DevicePart*> copying;
-    for (DevicePart& p : d->parts) {
+    for (size_t i = 0; i < d->parts.size(); i++) {
+        DevicePart& p = d->parts[i];
         if (at >= n) break;
-        uint64_t take = p.found < n - at ? p.found : n - at;
+        uint64_t take = cur.part_found[i] < n - at ? cur.part_found[i] : n - at;
         if (take == 0) continue;
         HIP_TRY(d->err, hipSetDevice(p.device));
-        HIP_TRY(d->err, hipMemcpyAsync(out + at, p.d_hits, (size_t)take * sizeof(uint64_t), hipMemcpyDeviceToHost, p.stream));
+        HIP_TRY(d->err, hipMemcpyAsync(out + at, cur.part_records[i], (size_t)take * sizeof(uint64_t), hipMemcpyDeviceToHost, p.abort_stream));
         copying.push_back(&p);
         at += take;
     }
     for (DevicePart* p : copying) {
         HIP_TRY(d->err, hipSetDevice(p->device));
-        HIP_TRY(d->err, hipStreamSynchronize(p->stream));
+        HIP_TRY(d->err, hipStreamSynchronize(p->abort_stream));
     }
     return HAVAC_OK;
 }
@@ -1713,15 +1843,8 @@ extern "C" int havac_dev_read_hits(havac_dev* d, uint64_t* out, uint32_t n) { re
 
 extern "C" int havac_dev_last_run_ms(havac_dev* d, float* ssv_kernel_ms, float* total_ms) {
     if (!d) return HAVAC_E_ARGUMENT;
-    if (!d->has_run || !d->finished) { d->err = "no finished run"; return HAVAC_E_LOGIC; }
-    float k = 0.f, t = 0.f;
-    for (DevicePart& p : d->parts) {     // the slowest GPU
-        float a = 0.f, b = 0.f;
-        havac_ssv_last_ms(p.ctx, &a, &b);
-        if (a > k) k = a;
-        if (b > t) t = b;
-    }
-    if (ssv_kernel_ms) *ssv_kernel_ms = k;
-    if (total_ms) *total_ms = t;
+    if (!d->has_run || d->runs.empty() || !d->runs.front().finished) { d->err = "no finished run"; return HAVAC_E_LOGIC; }
+    if (ssv_kernel_ms) *ssv_kernel_ms = d->runs.front().ssv_ms;
+    if (total_ms) *total_ms = d->runs.front().total_ms;
     return HAVAC_OK;
 }

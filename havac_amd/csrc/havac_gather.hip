@@ -244,6 +244,13 @@ extern "C" int havac_gather_create(uint32_t rank, uint32_t world, const uint8_t 
     return HAVAC_OK;
 }
 
+extern "C" int havac_gather_info(havac_gather* g, uint32_t* rank, uint32_t* world) {
+    if (!g) return HAVAC_E_ARGUMENT;
+    if (rank) *rank = g->rank;
+    if (world) *world = g->world;
+    return HAVAC_OK;
+}
+
 extern "C" const char* havac_gather_last_error(havac_gather* g) { return g ? g->err.c_str() : "null gather handle"; }
 
 // Step 1: every rank tells how many records its pass left (a negative count: the pass failed).  The one host wait of a gather.

@@ -163,6 +163,21 @@ void Havac::runHardwareClientAsync() {
         throw std::logic_error("Sequence was not loaded to device before hardware was requested to run.");
     needDevice();
     check(havac_dev_run_async(dev_));
+    // the models this run's hits belong to (host/Havac.cpp:104-116 makes the prefix sums when the hits are fetched; here the
+    // model list may have been replaced by then)
+    RunModels m;
+    m.prefixSums = generatePhmmLenPrefixSums();
+    for (uint32_t i = 0; i < p7HmmList->count; i++) m.lengths.push_back(p7HmmList->phmms[i].header.modelLength);
+    m.starts = modelStarts_;
+    if (pipelineDepth_ == 1) runModels_.clear();           // (the finished run before this one was closed by the device layer too)
+    runModels_.push_back(std::move(m));
+}
+
+void Havac::setPipelineDepth(uint32_t depth) {
+    needDevice();
+    check(havac_dev_set_pipeline_depth(dev_, depth));
+    pipelineDepth_ = depth;
+    runModels_.clear();
 }
 
 void Havac::waitHardwareClientAsync() { needDevice(); check(havac_dev_wait(dev_, 0)); }
@@ -267,7 +282,9 @@ vector<HavacHit> havacResolveHits(const vector<uint64_t> &rawHits, const FastaVe
     return resolveAll(rawHits.size(), [&](size_t i, HavacHit *hit) { return resolveOne(rawHits[i], i, fastaVector, phmmPrefixSums, hit); });
 }
 
-vector<HavacHit> Havac::getHitsFromFinishedRun() {
+vector<HavacHit> Havac::getHitsFromFinishedRun() { return fetchHits(nullptr); }
+
+vector<HavacHit> Havac::fetchHits(vector<uint32_t> *modelLengthsOut) {
     needDevice();
     uint64_t n = 0;                                        // 64-bit: several GPUs can hold more than 2^32 - 1 records
     check(havac_dev_num_hits64(dev_, &n));
@@ -294,8 +311,22 @@ vector<HavacHit> Havac::getHitsFromFinishedRun() {
         const uint64_t n = residueCounts_[h.sequenceIndex];
         if (h.sequencePosition < n) h.sequencePosition = n - 1 - h.sequencePosition;   // the terminator column stays
     };
+    // the models this run ran with (a run started before loadPhmm replaced them; with nothing recorded: the current ones)
+    RunModels models;
+    if (!runModels_.empty()) models = runModels_.front();
+    else {
+        models.prefixSums = generatePhmmLenPrefixSums();
+        for (uint32_t i = 0; i < p7HmmList->count; i++) models.lengths.push_back(p7HmmList->phmms[i].header.modelLength);
+        models.starts = modelStarts_;
+    }
+    if (modelLengthsOut) *modelLengthsOut = models.lengths;
+    // with several runs open, fetching a run's hits closes it: the next call speaks of the next run
+    struct CloseRun {
+        Havac *h;
+        ~CloseRun() { if (h->pipelineDepth_ > 1) { (void)havac_dev_retire(h->dev_); if (!h->runModels_.empty()) h->runModels_.pop_front(); } }
+    } closeRun{this};
     if (!boundaryMode_) {
-        vector<uint32_t> sums = generatePhmmLenPrefixSums();
+        vector<uint32_t> &sums = models.prefixSums;
         return resolveAll(raw.size(), [&](size_t i, HavacHit *hit) {
             bool isReverse;
             if (!resolveOne(fold(raw[i], &isReverse), i, fastaVector, sums, hit)) return false;
@@ -304,6 +335,7 @@ vector<HavacHit> Havac::getHitsFromFinishedRun() {
         });
     }
     // boundary mode: records and models have their own start tables (separators in between)
+    const vector<uint32_t> &modelStarts_ = models.starts;
     return resolveAll(raw.size(), [&](size_t i, HavacHit *hit) {
         bool isReverse;
         const uint64_t rec = fold(raw[i], &isReverse);
@@ -314,7 +346,7 @@ vector<HavacHit> Havac::getHitsFromFinishedRun() {
         if (j == 0 || k == 0) return false;
         j--; k--;
         if (column - recordStarts_[j] >= recordLengths_[j]) return false;                     // separator or padding column
-        if (row - modelStarts_[k] >= p7HmmList->phmms[k].header.modelLength) return false;    // separator row
+        if (row - modelStarts_[k] >= models.lengths[k]) return false;                         // separator row
         *hit = HavacHit(column - recordStarts_[j], (uint32_t)j, row - modelStarts_[k], (uint32_t)k);
         mirror(*hit, isReverse);
         return true;
@@ -370,9 +402,8 @@ vector<HavacWindow> havacMergeHitsToWindows(const vector<HavacHit> &hits, const 
 }
 
 vector<HavacWindow> Havac::getWindowsFromFinishedRun(uint32_t flank) {
-    vector<HavacHit> hits = getHitsFromFinishedRun();
     vector<uint32_t> modelLengths;
-    for (uint32_t i = 0; i < p7HmmList->count; i++) modelLengths.push_back(p7HmmList->phmms[i].header.modelLength);
+    vector<HavacHit> hits = fetchHits(&modelLengths);
     vector<uint64_t> recordLengths;
     size_t start = 0;
     for (size_t i = 0; i < fastaVector->metadata.count; i++) {          // end position is one past the terminator

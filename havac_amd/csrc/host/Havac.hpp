@@ -9,6 +9,7 @@
 #define HAVAC_HOST_HPP
 
 #include <cstdint>
+#include <deque>
 #include <memory>
 #include <string>
 #include <thread>
@@ -109,6 +110,13 @@ public:
     // on the GPU as well.  The device buffers are byte for byte what the host packer (SequencePreprocessor) would have
     // produced with the same rand() state.  Off = pack on the host.
     void setDevicePacking(bool on);
+    // Runs in flight (the reference's runHardwareClient is one run at a time, host/Havac.cpp:80-98): with a depth above 1
+    // runHardwareClientAsync may be called again -- after loadPhmm of the next model file, say -- before the hits of the run
+    // before are fetched.  The records of run k are then ordered and read back while the kernel of run k + 1 runs
+    // (include/havac_dev.h: havac_dev_set_pipeline_depth).  wait / state / abort / getHitsFromFinishedRun speak of the OLDEST run
+    // whose hits have not been fetched; getHitsFromFinishedRun waits for it if need be, resolves its hits against the models IT
+    // ran with, and closes it.  Depth 1 (the default) is the reference's behaviour in every respect.  Call between runs.
+    void setPipelineDepth(uint32_t depth);
     void setHitCapacity(uint64_t maxHits);                 // the reference's buffer is a fixed 3.5 GiB
     void lastRunMilliseconds(float *ssvKernelMs, float *totalMs);
     const vector<uint64_t> &rawHitsOfLastFetch() const { return rawHits_; }
@@ -137,6 +145,11 @@ private:
     vector<uint64_t> residueCounts_;                       // both strands: residues per record
     vector<uint64_t> recordStarts_, recordLengths_;        // boundary mode: global column of each record
     vector<uint32_t> modelStarts_;                         // boundary mode: global row of each model
+    // what a run's hits are resolved against: the models it was started with (loadPhmm may have replaced them since)
+    struct RunModels { vector<uint32_t> prefixSums, lengths, starts; };
+    std::deque<RunModels> runModels_;                      // one per open run, oldest first
+    uint32_t pipelineDepth_ = 1;
+    vector<HavacHit> fetchHits(vector<uint32_t> *modelLengthsOut);
 };
 
 // The resolver of host/Havac.cpp:145-187 as a free function (testable without a device):

@@ -18,6 +18,7 @@ struct havac_host {
     std::string err;
     vector<HavacHit> hits;
     bool haveHits = false;
+    uint32_t depth = 1;
 };
 
 namespace {
@@ -97,6 +98,19 @@ int havac_host_run_async(havac_host *h) { h->haveHits = false; return guarded(h,
 int havac_host_wait(havac_host *h) { return guarded(h, [&] { h->obj->waitHardwareClientAsync(); }); }
 int havac_host_abort(havac_host *h) { return guarded(h, [&] { h->obj->abortHardwareClient(); }); }
 int havac_host_set_hit_capacity(havac_host *h, uint64_t n) { return guarded(h, [&] { h->obj->setHitCapacity(n); }); }
+int havac_host_set_pipeline_depth(havac_host *h, uint32_t depth) {
+    const int rc = guarded(h, [&] { h->obj->setPipelineDepth(depth); });
+    if (rc == HAVAC_OK) { h->depth = depth; h->haveHits = false; }
+    return rc;
+}
+// With several runs open havac_host_get_hits fetches (and closes) the oldest run once and then serves the copy it keeps -- a
+// caller asks twice, for the count and for the arrays; this says the caller is done with that run: the next havac_host_get_hits
+// fetches the next one.  At depth 1 the copy is kept until the next run, as the reference's getHitsFromFinishedRun can be
+// called again and again.
+int havac_host_next_run(havac_host *h) {
+    if (h->depth > 1) h->haveHits = false;
+    return HAVAC_OK;
+}
 int havac_host_set_both_strands(havac_host *h, int on) { return guarded(h, [&] { h->obj->setBothStrands(on != 0); }); }
 int havac_host_get_hit_strands(havac_host *h, uint8_t *reverse, uint32_t cap, uint32_t *count) {
     if (count) *count = (uint32_t)h->hits.size();

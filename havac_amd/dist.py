@@ -262,132 +262,166 @@ def gather_hits(local_hits: torch.Tensor, local_count: int, group=None, out: tor
     return (merged.to(out_dev) if dev != out_dev else merged), counts
 
 
-TWO_STREAMS_FROM_CELLS = 4e10     # per shard: from here on consecutive passes' kernels run side by side (ShardedSsv)
+_NO_STREAM = C.c_void_p(-1)      # include/havac_dev.h: HAVAC_NO_STREAM
 
 
-def from_cells(nsymbols, nrows, rank, world):
-    from .ssv import shard_cells
-    return shard_cells(nsymbols, nrows, rank, world)
+class _DeviceRecords:
+    """`count` packed records at a device address that libhavac_dev.so owns, for torch.as_tensor (no copy)"""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<i8", "data": (ptr, False), "version": 2}
 
 
-class _Slot:
-    def __init__(self, hit_capacity, device, own_stream):
-        from .ssv import SsvContext
-        self.ctx = SsvContext()
-        self.hits = torch.empty(hit_capacity, dtype=torch.int64, device=device)
-        # the slot's own stream: the ordering of its records and their gather (low priority: what it runs fills the
-        # gaps the SSV kernels leave, it does not compete with them for compute units)
-        low, _high = torch.cuda.Stream.priority_range()
-        self.stream = torch.cuda.Stream(device, priority=low) if own_stream else None
-        if self.stream is not None:
-            self.ctx.set_order_stream(self.stream.cuda_stream)
-        self.merged = None               # rank 0: receive buffer of the gather, grown on demand and kept
-        self.gather_events = None        # (before, after) on the stream the gather ran on
+_views = {}      # (device address, device) -> (a tensor over the buffer as far as it has been asked for, its length)
+
+
+def _records_tensor(ptr: int, count: int, device: torch.device, capacity: int = 0) -> torch.Tensor:
+    """the first `count` records at `ptr` as a tensor: a slice of one cached view per buffer (making a tensor from a raw address
+    costs ~10 us, a slice 2: this sits on the strictly serial path)"""
+    if count == 0 or not ptr:
+        return torch.empty(0, dtype=torch.int64, device=device)
+    key = (ptr, device.index)
+    view = _views.get(key)
+    if view is None or view.numel() < count:
+        if len(_views) > 64:
+            _views.clear()
+        view = torch.as_tensor(_DeviceRecords(ptr, max(count, capacity)), device=device)     # (capacity: what the buffer is known to hold)
+        _views[key] = view
+    return view[:count]
 
 
 class ShardedSsv:
     """Rank-local driver: enqueue this rank's shard, order its hits, gather to rank 0 (already in order).
 
-    depth > 1 keeps that many passes in flight, each with its own context, hit buffer and ordering stream:
-    ``submit`` enqueues a pass, ``collect`` finishes the oldest one.  While the host waits for pass k's hit count,
-    orders its records and (N > 1) gathers them over RCCL, the SSV kernel of pass k+1 is already running.  The SSV
-    kernels of consecutive passes alternate between two high-priority streams -- a kernel starts as its predecessor
-    drains -- and never wait behind another pass's ordering (havac_ssv_set_order_stream puts that on the slot's own
-    low-priority stream).  A kernel's event-timed duration includes what its neighbours took of the chip meanwhile; a
-    depth-1 engine measures a kernel alone.
+    A thin binding of libhavac_dev.so's pipe (include/havac_dev.h level 2b, havac_amd/csrc/havac_pipe.hip): the slots -- a
+    context, a hit buffer and an ordering stream each --, the kernel streams and the bookkeeping of passes in flight live in
+    C++ since round 5, so that a C++ caller of the drop-in API gets the same engine (havac_dev_set_pipeline_depth).
+    depth > 1 keeps that many passes in flight: ``submit`` enqueues a whole pass, ``collect`` finishes the oldest one.  While
+    the host waits for pass k and its records are ordered and (N > 1) gathered over RCCL, the SSV kernel of pass k+1 is
+    already running; the kernels of consecutive passes alternate between two high-priority streams where passes are long
+    enough to gain from it (kernel_streams: None = the library's rule, two from 4e10 cells per shard on; 1; 2).  A kernel's
+    event-timed duration then includes what its neighbours took of the chip meanwhile; a depth-1 engine measures a kernel alone.
 
-    The records ``collect`` returns live in the slot's receive buffer (world > 1) or hit buffer (world == 1): they
-    are valid until that slot is submitted again, and the caller's current stream has been made to wait for them."""
+    The records ``collect`` returns live in libhavac_dev.so's buffers (the slot's hit buffer, or rank 0's receive buffer):
+    they are valid until that slot is submitted again, and the caller's current stream has been made to wait for them.
+
+    The gather goes through libhavac_dev.so's own RCCL calls (route "c_abi": the nccl backend, or any backend once
+    use_gather_library() named a stand-in) -- then it, too, is the pipe's business -- or through torch.distributed (gloo in the
+    CPU tests and rehearsals; set_gather_route("torch"))."""
 
     def __init__(self, hit_capacity: int, device: torch.device, depth: int = 1, gather_when_alone: bool = False, tuning=None,
                  kernel_streams: int | None = None):
-        """tuning: optional (rows_per_block, tiles_per_item, block_tails, ordering[, parts_log2, split_rounds_x4, short_rows, guide])
-        for SsvContext.set_tuning / set_split_tuning (experiments)"""
+        """tuning: optional (rows_per_block, tiles_per_item, block_tails, ordering[, parts_log2, split_rounds_x4, short_rows, guide[, variant]])
+        for SsvContext.set_tuning / set_split_tuning / set_kernel_variant (experiments)"""
+        from . import _lib
+        from .ssv import SsvContext
+        if kernel_streams not in (None, 1, 2):
+            raise ValueError("kernel_streams: None (the library's rule), 1 or 2")
+        self._L = _lib.load()
         self.device = device
+        self.depth = max(1, depth)
         # rehearsals on one GPU: run the collectives even in a one-rank group
         self.gather_when_alone = gather_when_alone and dist.is_initialized()
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.slots = [_Slot(hit_capacity, device, depth > 1) for _ in range(max(1, depth))]
-        if tuning:
-            for slot in self.slots:
-                slot.ctx.set_tuning(*tuning[:4])
+        self._gathers = self.world > 1 or self.gather_when_alone
+        h = C.c_void_p()
+        torch.cuda.set_device(device)        # (the pipe lives on the device that is current now; submit / collect make it current themselves)
+        rc = self._L.havac_pipe_create(self.depth, hit_capacity, -1 if kernel_streams is None else kernel_streams, C.byref(h))
+        if rc != 0:
+            from .hw_client import raise_for
+            raise_for(rc, "could not create the pipe (no gfx950 device, or out of memory)")
+        self._h = h
+        self._capacity = hit_capacity
+        self.slots = list(range(self.depth))                 # (bench.py looks at len(engine.slots))
+        self.in_flight = []                                   # slot numbers, oldest first (a mirror of the pipe's own)
+        self._next = 0
+        self._contexts = [SsvContext.borrowed(self._L.havac_pipe_context(self._h, k)) for k in range(self.depth)]
+        for ctx in self._contexts:
+            if tuning:
+                ctx.set_tuning(*tuning[:4])
                 if len(tuning) > 4:
-                    slot.ctx.set_split_tuning(*tuning[4:8])
+                    ctx.set_split_tuning(*tuning[4:8])
                 if len(tuning) > 8:
-                    slot.ctx.set_kernel_variant(tuning[8])
-        _low, high = torch.cuda.Stream.priority_range()
-        self.kernel_stream = torch.cuda.Stream(device, priority=high) if depth > 1 else None
-        # Consecutive passes' kernels alternate between TWO high-priority streams (round 4): a kernel then starts while its
-        # predecessor drains -- the last, half-empty round of a launch's tiles and the ~25 us between two dependent launches
-        # are filled by its neighbour's first workgroups -- instead of behind its end: C2 1.878 -> 1.834 ms per step, less than
-        # one kernel takes alone (1.850).  A kernel's event-timed duration then includes its neighbour's share of the chip;
-        # the duration of a kernel ALONE is what a depth-1 engine measures (bench.py does, for `roofline`).
-        # kernel_streams = 1: one stream, kernels back to back, never side by side (rounds 2-3) -- what passes of a fraction of a
-        # millisecond want: two 0.13 ms kernels side by side, each with its preparation and its tails behind it, get in each
-        # other's way (a 64-row model x 100 Mbp: 0.221 against 0.200 ms per step; 256 rows: -4 %).  None (the default): the
-        # library's rule, per pass -- two streams from 4e10 cells per shard on (512 rows x 100 Mbp: +1.8 %, 1024 rows: +3.5 %).
-        if kernel_streams not in (None, 1, 2):
-            raise ValueError("kernel_streams: None (the library's rule), 1 or 2")
-        self.kernel_streams = kernel_streams
-        self.kernel_stream2 = torch.cuda.Stream(device, priority=high) if depth > 1 and kernel_streams != 1 else None
-        self.used_two_streams = False
-        self._flip = 0
-        self.in_flight = []               # slot indices, oldest first
-        self.next_slot = 0
-        self.ctx = self.slots[0].ctx      # the context of the most recently collected pass (for last_ms)
-        self.hits = self.slots[0].hits
+                    ctx.set_kernel_variant(tuning[8])
+        self.ctx = self._contexts[0]      # the context of the most recently collected pass (for last_ms)
+        self._c_route = False
+        self._py_streams, self._merged = [None] * self.depth, [None] * self.depth
+        if self._gathers:
+            g = c_gather(None) if _c_route(None) else None
+            if g is not None:
+                self._c_route = True
+                self._check(self._L.havac_pipe_set_gather(self._h, g._h))
+            elif self.depth > 1:      # the torch route: the gather of a slot runs on a low-priority stream of its own
+                low, _high = torch.cuda.Stream.priority_range()
+                self._py_streams = [torch.cuda.Stream(device, priority=low) for _ in range(self.depth)]
         self.gather_ms = []               # device time of each gather on this rank (filled by gather_times())
         self._timed = []
+
+    def _check(self, rc):
+        if rc < 0:
+            from .hw_client import raise_for
+            raise_for(rc, (self._L.havac_pipe_last_error(self._h) or b"").decode())
+
+    @property
+    def used_two_streams(self) -> bool:
+        return bool(self._L.havac_pipe_used_two_streams(self._h))
 
     def set_sequence_window(self, first_column: int = 0, ncolumns: int = 0):
         """the d_seq handed to submit() holds columns [first_column, first_column + ncolumns) of the database only
         (havac_amd.ssv.shard_window tells a rank what it needs: its shard, the left halo, a little for the tiling)"""
-        for slot in self.slots:
-            slot.ctx.set_sequence_window(first_column, ncolumns)
+        for ctx in self._contexts:
+            ctx.set_sequence_window(first_column, ncolumns)
 
-    def submit(self, d_seq: torch.Tensor, nsymbols: int, d_phmm: torch.Tensor, nrows: int):
-        if len(self.in_flight) == len(self.slots):
+    def submit(self, d_seq: torch.Tensor, nsymbols: int, d_phmm: torch.Tensor, nrows: int, inputs_ready: bool = False):
+        """inputs_ready: d_seq and d_phmm are in place (the caller has synchronised since they were written): the pass does not
+        wait for the caller's current stream -- an event on torch's default stream costs a short pass several per cent"""
+        if len(self.in_flight) == self.depth:
             raise RuntimeError("every slot is in flight: collect() first")
-        slot = self.slots[self.next_slot]
-        stream = self.kernel_stream if self.kernel_stream is not None else torch.cuda.current_stream(self.device)
-        if self.kernel_stream2 is not None and (self.kernel_streams == 2 or
-                                                from_cells(nsymbols, nrows, self.rank, self.world) >= TWO_STREAMS_FROM_CELLS):
-            self.used_two_streams = True
-            self._flip ^= 1
-            if self._flip:
-                stream = self.kernel_stream2
-        if self.kernel_stream is not None:
-            stream.wait_stream(torch.cuda.current_stream(self.device))      # the caller's inputs
-            if self.world > 1 or self.gather_when_alone:
-                stream.wait_stream(slot.stream)                              # the slot's last gather has read its hit buffer
-                #                                                              (alone, collect() has waited for the ordering on the host)
-        slot.ctx.enqueue(d_seq.data_ptr(), nsymbols, d_phmm.data_ptr(), nrows, slot.hits.data_ptr(),
-                         slot.hits.numel(), self.rank, self.world, 0, stream.cuda_stream)
-        self.in_flight.append(self.next_slot)
-        self.next_slot = (self.next_slot + 1) % len(self.slots)
+        slot = self._next
+        wait_for = _NO_STREAM
+        if self._py_streams[slot] is not None or not inputs_ready:
+            current = torch.cuda.current_stream(self.device)
+            if self._py_streams[slot] is not None:
+                current.wait_stream(self._py_streams[slot])          # the slot's last gather (torch route) has read its hit buffer
+            wait_for = current.cuda_stream or None
+        self._check(self._L.havac_pipe_submit(self._h, d_seq.data_ptr(), nsymbols, d_phmm.data_ptr(), nrows, self.rank, self.world,
+                                              None, wait_for))
+        self.in_flight.append(slot)
+        self._next = (slot + 1) % self.depth
 
     def collect(self):
         """-> (records on rank 0 in device order or None, hits found by this rank) of the oldest pass in flight.
         If the pass failed on any rank, every rank raises (this rank's own error, or ShardFailure)."""
-        slot = self.slots[self.in_flight.pop(0)]
-        error = None
-        try:
-            found = slot.ctx.finish()
-        except Exception as e:            # still take part in the collectives below: the other ranks are in them
-            error, found = e, FAILED
-        self.ctx, self.hits = slot.ctx, slot.hits
-        if self.world == 1 and not self.gather_when_alone:
-            if error is not None:
-                raise error
-            return slot.hits[:found], found
+        slot = self.in_flight.pop(0)
         current = torch.cuda.current_stream(self.device)
-        stream = slot.stream if slot.stream is not None else current
+        found, ptr, n = C.c_uint64(0), C.c_void_p(), C.c_uint64(0)
+        error = None
+        rc = self._L.havac_pipe_collect(self._h, C.byref(found), C.byref(ptr), C.byref(n), current.cuda_stream or None)
+        self.ctx = self._contexts[slot]
+        if rc < 0:
+            try:
+                self._check(rc)
+            except Exception as e:      # noqa: BLE001 -- the torch route still has collectives to take part in
+                error = e
+        if not self._gathers or self._c_route:
+            if error is not None:
+                if "the pass failed on rank(s)" in str(error):
+                    raise ShardFailure(str(error))
+                raise error
+            if not self._gathers:
+                return _records_tensor(ptr.value, found.value, self.device, self._capacity), found.value
+            return (_records_tensor(ptr.value, n.value, self.device) if self.rank == 0 else None), found.value
+        # the torch route (gloo rehearsals; set_gather_route("torch")): the pipe ordered this rank's records, torch.distributed moves them
+        local = _records_tensor(ptr.value, found.value, self.device, self._capacity) if error is None else torch.empty(0, dtype=torch.int64, device=self.device)
+        stream = self._py_streams[slot] if self._py_streams[slot] is not None else current
         try:
             with torch.cuda.stream(stream):
+                if stream is not current:
+                    stream.wait_stream(current)
                 before, after = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 before.record(stream)
-                merged, counts = gather_hits(slot.hits, found, out=slot.merged)
+                merged, counts = gather_hits(local, FAILED if error is not None else found.value, out=self._merged[slot])
                 after.record(stream)
         except ShardFailure:
             if error is not None:
@@ -395,25 +429,65 @@ class ShardedSsv:
             raise
         self._timed.append((before, after))
         if merged is not None:
-            if slot.merged is None or merged.numel() > slot.merged.numel():
-                slot.merged = merged
+            if self._merged[slot] is None or merged.numel() > self._merged[slot].numel():
+                self._merged[slot] = merged
             if stream is not current:      # hand the records over to the caller's stream
                 current.wait_stream(stream)
                 merged.record_stream(current)
-        return merged, found
+        return merged, found.value
+
+    def run_many(self, nsteps: int, d_seq: torch.Tensor, nsymbols: int, d_phmm: torch.Tensor, nrows: int, inputs_ready: bool = False):
+        """`nsteps` passes of the same inputs, as many in flight as the engine is deep, all complete on return
+        -> ((records on rank 0 or None, hits found by this rank) of the last pass, [(kernel ms, enqueue-to-ordered ms)] per pass).
+        Where the pipe does the gather itself (or there is none) the loop runs inside libhavac_dev.so (havac_pipe_run): a timed
+        region without Python in it, i.e. what a C++ caller of the library gets."""
+        if self.in_flight:
+            raise RuntimeError("passes are in flight: collect() them first")
+        if self._gathers and not self._c_route:      # the torch route gathers in Python, pass by pass
+            result, timings = None, []
+            for _ in range(nsteps):
+                self.submit(d_seq, nsymbols, d_phmm, nrows, inputs_ready)
+                if len(self.in_flight) == self.depth:
+                    result = self.collect()
+                    timings.append(self.ctx.last_ms())
+            while self.in_flight:
+                result = self.collect()
+                timings.append(self.ctx.last_ms())
+            return result, timings
+        current = torch.cuda.current_stream(self.device)
+        k_ms, t_ms = (C.c_float * max(1, nsteps))(), (C.c_float * max(1, nsteps))()
+        found, ptr, n = C.c_uint64(0), C.c_void_p(), C.c_uint64(0)
+        rc = self._L.havac_pipe_run(self._h, nsteps, d_seq.data_ptr(), nsymbols, d_phmm.data_ptr(), nrows, self.rank, self.world,
+                                    _NO_STREAM if inputs_ready and not self._gathers else (current.cuda_stream or None), k_ms, t_ms,
+                                    C.byref(found), C.byref(ptr), C.byref(n))
+        self._next = (self._next + nsteps) % self.depth
+        self.ctx = self._contexts[(self._next - 1) % self.depth]
+        if rc < 0:
+            try:
+                self._check(rc)
+            except Exception as e:      # noqa: BLE001
+                if "the pass failed on rank(s)" in str(e):
+                    raise ShardFailure(str(e))
+                raise
+        timings = [(k_ms[i], t_ms[i]) for i in range(nsteps)]
+        if not self._gathers:
+            return (_records_tensor(ptr.value, found.value, self.device, self._capacity), found.value), timings
+        return ((_records_tensor(ptr.value, n.value, self.device) if self.rank == 0 else None), found.value), timings
 
     def wait_gathers(self):
         """The records of the last collected pass may still be travelling (the gather is enqueued, not waited for): waits for
         them with the gather's deadline (set_gather_deadline; hw_client.CollectiveTimeout names rank and stage) -- before a
         device-wide synchronise, which a peer that died would never let return."""
-        if self.world == 1 and not self.gather_when_alone:
-            return
-        g = _c_gathers.get(None)
-        if g is not None:
-            g.wait()
+        if self._c_route:
+            self._check(self._L.havac_pipe_wait_gathers(self._h))
 
     def gather_times(self):
         """device milliseconds of every gather so far (synchronises the events)"""
+        if self._c_route:
+            n = C.c_uint32(0)
+            buf = (C.c_float * 4096)()
+            self._check(self._L.havac_pipe_gather_times(self._h, buf, 4096, C.byref(n)))
+            self.gather_ms.extend(buf[: min(n.value, 4096)])
         for before, after in self._timed:
             after.synchronize()
             self.gather_ms.append(before.elapsed_time(after))
@@ -427,16 +501,18 @@ class ShardedSsv:
 
     def release(self):
         """Gives the device memory of every slot back: contexts with their ordering buffers, hit buffers, receive buffers.
-        The records collect() returned last stay valid for as long as the caller holds that tensor (it keeps its buffer
-        alive); everything else is freed now, not when the engine is collected.  Nothing may be in flight."""
+        The records collect() returned last stay valid until close(); everything else is freed now.  Nothing may be in
+        flight, and nothing can be submitted afterwards."""
         if self.in_flight:
             raise RuntimeError("passes are in flight: collect() them first")
-        for slot in self.slots:
-            slot.ctx.close()
-            slot.hits = slot.merged = None
-        self.hits = None
+        self._check(self._L.havac_pipe_release(self._h))
+        self._merged = [None] * self.depth
+        _views.clear()
         torch.cuda.empty_cache()
 
     def close(self):
-        for slot in self.slots:
-            slot.ctx.close()
+        if getattr(self, "_h", None):
+            self._L.havac_pipe_destroy(self._h)
+            self._h = None
+
+    __del__ = close

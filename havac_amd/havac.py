@@ -33,6 +33,8 @@ HOST_SIGNATURES = {
     "havac_host_abort": (C.c_int, [_vp]),
     "havac_host_state": (C.c_int, [_vp]),
     "havac_host_set_hit_capacity": (C.c_int, [_vp, C.c_uint64]),
+    "havac_host_set_pipeline_depth": (C.c_int, [_vp, C.c_uint32]),
+    "havac_host_next_run": (C.c_int, [_vp]),
     "havac_host_set_boundary_mode": (C.c_int, [_vp, C.c_int]),
     "havac_host_set_both_strands": (C.c_int, [_vp, C.c_int]),
     "havac_host_set_device_packing": (C.c_int, [_vp, C.c_int]),
@@ -163,6 +165,10 @@ class Havac:
     def setHitCapacity(self, n: int):
         self._check(self._L.havac_host_set_hit_capacity(self._h, n))
 
+    def setPipelineDepth(self, depth: int):
+        """runs in flight (Havac::setPipelineDepth; 1 = the reference's one at a time)"""
+        self._check(self._L.havac_host_set_pipeline_depth(self._h, depth))
+
     def getHitsFromFinishedRun(self):
         n = C.c_uint32(0)
         self._check(self._L.havac_host_get_hits(self._h, None, None, None, None, 0, C.byref(n)))
@@ -172,6 +178,7 @@ class Havac:
                                                 pi.ctypes.data, n.value, C.byref(n)))
         rev = np.zeros(n.value, np.uint8)
         self._check(self._L.havac_host_get_hit_strands(self._h, rev.ctypes.data, n.value, C.byref(n)))
+        self._L.havac_host_next_run(self._h)      # (several runs open: the next call fetches the next run)
         return [HavacHit(int(a), int(b), int(c), int(d), bool(e)) for a, b, c, d, e in zip(sp, si, pp, pi, rev)]
 
     def getWindowsFromFinishedRun(self, flank: int = 0):

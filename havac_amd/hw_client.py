@@ -89,6 +89,17 @@ class HavacHwClient:
     def setHitCapacity(self, max_hits: int):
         self._check(self._L.havac_dev_set_hit_capacity(self._h, int(max_hits)))
 
+    def setPipelineDepth(self, depth: int):
+        """Not in the reference (include/havac_dev.h: havac_dev_set_pipeline_depth): up to `depth` runs open at once; the other
+        methods speak of the oldest open run, retire() closes it."""
+        self._check(self._L.havac_dev_set_pipeline_depth(self._h, int(depth)))
+
+    def retire(self):
+        self._check(self._L.havac_dev_retire(self._h))
+
+    def openRuns(self) -> int:
+        return int(self._L.havac_dev_open_runs(self._h))
+
     def setTuning(self, *values: int):
         """experiment knobs (include/havac_dev.h: havac_dev_set_tuning): rows_per_block, tiles_per_item, block_tails, ordering,
         parts_log2, split_rounds_x4, short_rows, guide, kernel variant (0 standard, 1 short-model); -1 or missing = the library's own rule"""

@@ -21,9 +21,19 @@ class SsvContext:
             raise_for(rc, "could not create an SSV context (no gfx950 device?)")
         self._h = h
 
+    @classmethod
+    def borrowed(cls, handle):
+        """a context that somebody else owns (a slot of a pipe: havac_pipe_context); close() leaves it alone"""
+        self = cls.__new__(cls)
+        self._L = _lib.load()
+        self._h = C.c_void_p(handle)
+        self._borrowed = True
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            self._L.havac_ssv_ctx_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._L.havac_ssv_ctx_destroy(self._h)
             self._h = None
 
     __del__ = close

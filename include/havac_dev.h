@@ -7,7 +7,8 @@
  * Plain pointers and sizes only; no C++, HIP or torch types cross it.  The
  * reference-side binding a maintainer would add is shown in INTEGRATION.md.
  *
- * Three levels are exported by libhavac_dev.so (the third -- the RCCL gather of a sharded run -- at the end of this file):
+ * Three levels are exported by libhavac_dev.so (the third -- the RCCL gather of a sharded run -- at the end of this file; between
+ * the second and the third, "2b": several passes in flight):
  *
  *  1. havac_dev_*   one opaque handle per `Havac` object; one entry point per
  *                   HavacHwClient method the `Havac` class calls
@@ -159,6 +160,22 @@ int havac_dev_write_phmm(havac_dev *dev, const int8_t *scores, uint64_t nbytes);
  * Enqueues on the handle's private stream and returns. */
 int havac_dev_run_async(havac_dev *dev);
 
+/* Optional, not in the reference, whose client runs one pass at a time (host/HavacHwClient.cpp:141-157): up to `depth` runs open at
+ * once (1, the default, ... 4).  havac_dev_run_async may then be called again while earlier runs are still on the device -- the
+ * records of run k are ordered and read back while the kernel of run k + 1 runs, which itself started while kernel k was draining
+ * (level 2b below: every GPU of the handle gets a pipe of `depth` slots, a hit buffer of the handle's capacity each).  All other
+ * entry points -- state, wait, abort, num_hits, read_hits, last_run_ms -- speak of the OLDEST open run; havac_dev_retire closes
+ * it (waiting for it if need be) and makes the next one current.  Results are retrieved in submission order.  At depth 1
+ * nothing changes: a finished run is closed by the next havac_dev_run_async, as the reference's run object is overwritten by
+ * the next invokeHavacSsvAsync.  The inputs may be rewritten between runs while earlier runs are in flight: a write waits until
+ * those runs have READ what it overwrites (the model: a pass's first kernel; the sequence: its SSV kernel), not until they have
+ * finished.  havac_dev_abort stops every run in flight.  Changing the depth (or the hit capacity) needs every open run finished
+ * and drops their lists. */
+int havac_dev_set_pipeline_depth(havac_dev *dev, uint32_t depth);
+uint32_t havac_dev_pipeline_depth(havac_dev *dev);
+int havac_dev_retire(havac_dev *dev);
+uint32_t havac_dev_open_runs(havac_dev *dev);
+
 /* HavacHwClient::getHwState  host/HavacHwClient.cpp:163-170.
  * Returns a HAVAC_STATE_* value (>0) or a negative error (LOGIC when no run
  * was ever started, as the reference throws). */
@@ -247,6 +264,12 @@ int havac_ssv_set_separator_mask(havac_ssv_ctx *ctx, const uint8_t *d_pair_bitma
  * ordering stream: the kernel of pass k+1 then never waits behind the ordering of pass k (bench.py, havac_amd/dist.py).
  * No counterpart in the reference (one run at a time, host/HavacHwClient.cpp:150-170). */
 int havac_ssv_set_order_stream(havac_ssv_ctx *ctx, void *hip_stream);
+
+/* Optional, for callers that keep passes in flight with an ordering stream set: the pass's first kernel (the padded copy of the
+ * model, the cleared counters) runs on the ORDERING stream, as soon as that stream's earlier work is done, instead of on the
+ * enqueue's stream in front of the SSV kernel -- the enqueue's stream then carries nothing but SSV kernels, back to back.  The
+ * caller must have made the ordering stream wait for the inputs (d_phmm) itself; havac_pipe_submit does. */
+int havac_ssv_set_early_preparation(havac_ssv_ctx *ctx, int on);
 
 /* Per-cell trace: the counterpart of the reference's HAVAC_PER_CELL_DATA_TESTING build (device/PublicDefines.h:11,
  * device/HavacHls.cpp:388-399: every cell processor records prevValue, matchScore, cellValue, symbol, passesThreshold;
@@ -365,6 +388,14 @@ typedef struct havac_order_report {
 int havac_ssv_check_order(const uint64_t *d_records, uint64_t count, const uint64_t *rank_counts, const uint64_t *span_begin,
                           const uint64_t *span_end, uint32_t nranks, void *hip_stream, havac_order_report *report_out);
 
+/* Without waiting: 1 if the enqueued pass -- kernel and ordering -- has completed on the device (havac_ssv_finish will not block),
+ * 0 if not yet, negative on error. */
+int havac_ssv_query(havac_ssv_ctx *ctx);
+/* Waits until the enqueued pass has READ its inputs: the model (its padded copy is made by the pass's first kernel) and, with
+ * sequence_too != 0, the sequence (read by the SSV kernel).  The caller may overwrite those buffers afterwards, while the rest
+ * of the pass still runs.  Returns at once when nothing is enqueued. */
+int havac_ssv_wait_inputs(havac_ssv_ctx *ctx, int sequence_too);
+
 /* After the stream has been synchronised: device time of the last enqueue's
  * SSV kernel and of the whole enqueue, from HIP events recorded on that stream. */
 int havac_ssv_last_ms(havac_ssv_ctx *ctx, float *ssv_kernel_ms, float *total_ms);
@@ -380,6 +411,60 @@ int havac_ssv_shard_columns(uint64_t nsymbols, uint32_t shard_index, uint32_t sh
                             uint64_t *col_begin, uint64_t *col_end);
 
 const char *havac_ssv_ctx_last_error(havac_ssv_ctx *ctx);
+
+/* ------------------------------------------------------------------------
+ * Level 2b: passes in flight
+ * ---------------------------------------------------------------------- */
+/* No counterpart in the reference, whose API is one run at a time (host/HavacHwClient.cpp:141-157: invoke, wait, list).  A pipe
+ * keeps up to `depth` passes in flight on the device that is current when it is created, each in a slot of its own -- a context,
+ * a hit buffer of hit_capacity records, a low-priority stream for the ordering of its records and (sharded runs) their gather --
+ * with the SSV kernels of consecutive passes on one high-priority stream, or alternating between two (kernel_streams: 1, 2, or -1
+ * = the library's rule per pass: two from 4e10 cells per shard on): while the host waits for pass k, its records are ordered and
+ * gathered, the kernel of pass k + 1 runs -- and has started while kernel k was draining.  depth 1 is the reference's behaviour.
+ *
+ *   havac_pipe_submit   enqueues one whole pass (as havac_ssv_enqueue; all pointers are DEVICE pointers the caller keeps alive)
+ *                       behind what `caller_stream` holds now (the inputs' producer; HAVAC_NO_STREAM: nothing to wait for);
+ *                       HAVAC_E_LOGIC when every slot is in flight
+ *   havac_pipe_collect  completes the OLDEST pass in flight: waits for it and returns the hits it found and its records in device
+ *                       order -- the slot's hit buffer, or, with a gather set, on rank 0 the whole list of all ranks in one
+ *                       buffer (NULL elsewhere).  The records stay valid until that slot is submitted again (depth passes later);
+ *                       `caller_stream` has been made to wait for them.  With a gather set a rank whose pass failed still takes
+ *                       part in the count exchange, and every rank then returns an error: none is left inside a collective.
+ *   havac_pipe_poll     1 if havac_pipe_collect would not block for the device, 0 if it would, negative on error
+ *   havac_pipe_wait_inputs  waits until every pass in flight has read the model (and, sequence_too != 0, the sequence): the caller
+ *                       may then overwrite those buffers for the next submit
+ *   havac_pipe_context  a slot's context (for the tuning and window setters of level 2); which = -1: of the last collected pass
+ *   havac_pipe_set_gather   the communicator of a sharded run (level 3): collect() then gathers every pass's records to rank 0
+ *   havac_pipe_wait_gathers, havac_pipe_gather_times   the records of the last collected pass may still be travelling: waits for
+ *                       them with the gather's deadline; device milliseconds of the gathers so far (and forgets them)
+ *   havac_pipe_release  gives every buffer back but the one that holds the records the last collect returned (valid until
+ *                       havac_pipe_destroy); nothing may be in flight; the pipe cannot be submitted to again */
+typedef struct havac_pipe havac_pipe;
+typedef struct havac_gather havac_gather;
+#define HAVAC_NO_STREAM ((void *)(intptr_t)-1)      /* as `caller_stream`: the inputs are in place, there is nothing to wait for */
+int havac_pipe_create(uint32_t depth, uint64_t hit_capacity, int kernel_streams, havac_pipe **out);
+void havac_pipe_destroy(havac_pipe *pipe);
+int havac_pipe_submit(havac_pipe *pipe, const uint8_t *d_sequence, uint64_t nsymbols, const int8_t *d_phmm, uint32_t nrows,
+                      uint32_t shard_index, uint32_t shard_count, const uint32_t *d_abort_flag, void *caller_stream);
+int havac_pipe_collect(havac_pipe *pipe, uint64_t *found_out, const uint64_t **d_records_out, uint64_t *nrecords_out, void *caller_stream);
+/* `nsteps` passes of the same inputs, as many in flight as the pipe is deep, all complete on return (submit, and collect the
+ * oldest once every slot is in flight); kernel_ms / total_ms: nsteps entries each or NULL; the last pass's result as
+ * havac_pipe_collect returns it.  A timed region without the caller's language in it. */
+int havac_pipe_run(havac_pipe *pipe, uint32_t nsteps, const uint8_t *d_sequence, uint64_t nsymbols, const int8_t *d_phmm, uint32_t nrows,
+                   uint32_t shard_index, uint32_t shard_count, void *caller_stream, float *kernel_ms, float *total_ms,
+                   uint64_t *found_out, const uint64_t **d_records_out, uint64_t *nrecords_out);
+int havac_pipe_poll(havac_pipe *pipe);
+int havac_pipe_wait_inputs(havac_pipe *pipe, int sequence_too);
+uint32_t havac_pipe_depth(havac_pipe *pipe);
+uint32_t havac_pipe_in_flight(havac_pipe *pipe);
+int havac_pipe_used_two_streams(havac_pipe *pipe);
+havac_ssv_ctx *havac_pipe_context(havac_pipe *pipe, int which);
+int havac_pipe_set_gather(havac_pipe *pipe, havac_gather *gather);
+int havac_pipe_wait_gathers(havac_pipe *pipe);
+int havac_pipe_gather_times(havac_pipe *pipe, float *out_ms, uint32_t capacity, uint32_t *count);
+int havac_pipe_last_ms(havac_pipe *pipe, float *ssv_kernel_ms, float *total_ms);
+int havac_pipe_release(havac_pipe *pipe);
+const char *havac_pipe_last_error(havac_pipe *pipe);
 
 /* ------------------------------------------------------------------------
  * Level 3: the one exchange of a sharded run -- an RCCL gather of the hit records to rank 0
@@ -416,7 +501,6 @@ const char *havac_ssv_ctx_last_error(havac_ssv_ctx *ctx);
  *                            rehearsals of several ranks on ONE GPU, which RCCL refuses: tests/native/rccl_standin.cpp implements
  *                            the eleven bound entry points over shared memory.  An argument, not an environment variable. */
 #define HAVAC_GATHER_ID_BYTES 128
-typedef struct havac_gather havac_gather;
 int havac_gather_rccl_version(int *version);
 int havac_gather_unique_id(uint8_t id[HAVAC_GATHER_ID_BYTES]);
 int havac_gather_create(uint32_t rank, uint32_t world, const uint8_t id[HAVAC_GATHER_ID_BYTES], havac_gather **out);
@@ -425,6 +509,7 @@ int havac_gather_records(havac_gather *g, const uint64_t *d_records, uint64_t *d
 int havac_gather_set_deadline(havac_gather *g, uint32_t timeout_ms);
 int havac_gather_wait(havac_gather *g);
 int havac_gather_use_library(const char *path);
+int havac_gather_info(havac_gather *g, uint32_t *rank, uint32_t *world);
 const char *havac_gather_last_error(havac_gather *g);
 void havac_gather_destroy(havac_gather *g);
 

@@ -35,6 +35,11 @@ int havac_host_wait(havac_host *h);                                    /* waitHa
 int havac_host_abort(havac_host *h);                                   /* abortHardwareClient  :100-102 */
 int havac_host_state(havac_host *h);                                   /* currentHardwareState :190-192 */
 int havac_host_set_hit_capacity(havac_host *h, uint64_t max_hits);
+/* Havac::setPipelineDepth: runs in flight (not in the reference; 1 = one run at a time, as there) */
+int havac_host_set_pipeline_depth(havac_host *h, uint32_t depth);
+/* with several runs open: the caller is done with the hits havac_host_get_hits served (it keeps a copy, for the count-then-arrays
+ * pair of calls); the next havac_host_get_hits fetches the next run.  Nothing to do at depth 1. */
+int havac_host_next_run(havac_host *h);
 /* Havac::setBoundaryMode (not in the reference): score every (model, record) pair on its own; before the loads */
 int havac_host_set_boundary_mode(havac_host *h, int on);
 /* Havac::setBothStrands (not in the reference): also score every record's reverse complement; before loadSequence */

@@ -132,6 +132,88 @@ def test_abort_and_timeout(client):
     assert client.waitForHavacSsvAsync() == 4
 
 
+def test_runs_in_flight_behind_the_handle(oracle):
+    """havac_dev_set_pipeline_depth (round 5; no counterpart in the reference, whose client runs one pass at a time,
+    host/HavacHwClient.cpp:141-157): three runs with three different models, two of them open at once -- the model is rewritten
+    while the run before is still on the device --, results in submission order, each list equal to the checker's for ITS model;
+    then the one-at-a-time behaviour again at depth 1."""
+    from havac_amd.hw_client import HavacHwClient, LogicError
+    sym, model_a = small_inputs(nrows=300, nseg=40, seed=11)
+    model_b, _ = synth.dfam_like_model(77, 99)
+    model_c, cons_c = synth.dfam_like_model(1500, 5)
+    want = [oracle.ssv_fast(sym, m) for m in (model_a, model_b, model_c)]
+    assert want[0].size > 50 and not np.array_equal(want[0], want[1])
+    c = HavacHwClient()
+    c.setHitCapacity(1 << 20)
+    c.setPipelineDepth(2)
+    c.writeSequence(synth.pack_2bit(sym))
+    c.writePhmm(model_a)
+    c.invokeHavacSsvAsync()
+    c.writePhmm(model_b)                        # while run A is on the device: waits until A has read its model, not until A is done
+    c.invokeHavacSsvAsync()
+    assert c.openRuns() == 2
+    with pytest.raises(LogicError, match="during a run"):
+        c.setPipelineDepth(3)
+    assert c.waitForHavacSsvAsync() == 4
+    assert np.array_equal(c.getHitList(), want[0])              # the OLDEST run: model A
+    assert np.array_equal(c.getHitList(), want[0])              # ... as often as asked
+    c.writePhmm(model_c)
+    c.invokeHavacSsvAsync()                                     # both slots open, the oldest finished: it is closed to make room
+    assert c.openRuns() == 2
+    assert c.waitForHavacSsvAsync() == 4
+    assert np.array_equal(c.getHitList(), want[1])              # model B
+    ssv_ms, total_ms = c.lastRunMs()
+    assert 0 < ssv_ms <= total_ms
+    c.retire()
+    assert c.openRuns() == 1 and c.getHwState() in (3, 4)
+    assert np.array_equal(c.getHitList(), want[2])              # model C (getHitList waits)
+    c.retire()
+    assert c.openRuns() == 0
+    with pytest.raises(LogicError):
+        c.retire()
+    # abort with two runs in flight stops both
+    long_model, _ = synth.dfam_like_model(60_000, 1)
+    c.setHitCapacity(1 << 27)                                   # (a stopped sweep may still have queued more than the small buffer above holds)
+    c.writeSequence(synth.random_packed(2000 * synth.SEGMENT, 2))
+    c.writePhmm(long_model)
+    c.invokeHavacSsvAsync()
+    c.invokeHavacSsvAsync()
+    assert c.abort() == 6
+    c.retire()
+    assert c.waitForHavacSsvAsync() == 6
+    c.retire()
+    # back to one run at a time: the reference's behaviour, a finished run is closed by the next one
+    c.setPipelineDepth(1)
+    c.writeSequence(synth.pack_2bit(sym))
+    c.writePhmm(model_b)
+    c.invokeHavacSsvAsync()
+    assert c.waitForHavacSsvAsync() == 4 and np.array_equal(c.getHitList(), want[1])
+    c.writePhmm(model_a)
+    c.invokeHavacSsvAsync()
+    assert np.array_equal(c.getHitList(), want[0])
+    c.close()
+
+
+def test_runs_in_flight_over_several_gpus(oracle):
+    """the same with four device parts behind the handle (one GPU named four times): every part keeps two passes in flight"""
+    from havac_amd.hw_client import HavacHwClient
+    sym, model_a = small_inputs(nrows=400, nseg=16, seed=21)
+    model_b, _ = synth.dfam_like_model(130, 8)
+    want = [oracle.ssv_fast(sym, m) for m in (model_a, model_b)]
+    c = HavacHwClient(deviceIndices=[0, 0, 0, 0])
+    c.setHitCapacity(1 << 18)
+    c.setPipelineDepth(2)
+    c.writeSequence(synth.pack_2bit(sym))
+    for k in range(6):
+        c.writePhmm(model_a if k % 2 == 0 else model_b)
+        c.invokeHavacSsvAsync()
+        if c.openRuns() == 2:
+            assert np.array_equal(c.getHitList(), want[(k - 1) % 2])
+            c.retire()
+    assert np.array_equal(c.getHitList(), want[1])
+    c.close()
+
+
 # ---- the file-level Havac class --------------------------------------------------------------------
 
 def write_inputs(tmp_path, lengths, record_lengths, seed=0):
@@ -209,6 +291,63 @@ def test_havac_class_end_to_end(tmp_path, oracle):
     with pytest.raises(RuntimeError, match="Could not open fasta"):
         h.loadSequence(str(tmp_path / "missing.fa"))
     h.close()
+
+
+def test_havac_class_with_runs_in_flight(tmp_path, oracle):
+    """Havac::setPipelineDepth: the next model file is loaded and its run started before the hits of the run before are
+    fetched; every run's hits are resolved against the models IT ran with (the model list has been replaced by then)."""
+    from havac_amd import havac
+    fa, hmm1 = write_inputs(tmp_path, [60, 300, 150], [5000, 9000, 30000, 17])
+    sub = tmp_path / "two"
+    sub.mkdir()
+    _, hmm2 = write_inputs(sub, [220, 90], [100], seed=5)
+    single = []
+    for hmm in (hmm1, hmm2):
+        h = havac.Havac(0, 0.02)
+        h.setDevicePacking(False)
+        h.loadPhmm(hmm)
+        C.CDLL(None).srand(7)
+        h.loadSequence(fa)
+        h.runHardwareClient()
+        single.append((h.getHitsFromFinishedRun(), h.rawHits()))
+        h.close()
+    assert len(single[0][0]) > 10 and single[0][0] != single[1][0]
+    h = havac.Havac(0, 0.02)
+    h.setDevicePacking(False)
+    h.setPipelineDepth(2)
+    C.CDLL(None).srand(7)
+    h.loadSequence(fa)
+    h.loadPhmm(hmm1)
+    h.runHardwareClientAsync()
+    h.loadPhmm(hmm2)                                              # replaces the model list while run 1 is open
+    h.runHardwareClientAsync()
+    first = h.getHitsFromFinishedRun()
+    assert first == single[0][0] and np.array_equal(h.rawHits(), single[0][1])
+    second = h.getHitsFromFinishedRun()
+    assert second == single[1][0] and np.array_equal(h.rawHits(), single[1][1])
+    h.close()
+
+
+def test_havac_benchmark_repeats_with_runs_in_flight(tmp_path):
+    """`havac_benchmark --repeat N --depth D` (files through the Havac class) and `--raw` (the C ABI directly, on one of
+    bench.py's synthetic workloads written by tools/dump_workload.py): no Python in the process that runs."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from havac_amd import havac
+    fa, hmm = write_inputs(tmp_path, [100, 250], [200000], seed=3)
+    exe = os.path.join(os.path.dirname(havac.HOST_LIB_PATH), "havac_benchmark")
+    out = subprocess.run([exe, fa, hmm, "--repeat", "20", "--depth", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "20 more runs, 2 in flight" in out.stdout and "the same count every run: yes" in out.stdout
+    prefix = str(tmp_path / "w")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dump_workload.py"), "--rows", "256", "--columns-per-gpu", str(400 * synth.SEGMENT), prefix],
+                   check=True, capture_output=True, timeout=300)
+    for depth in ("1", "2"):
+        out = subprocess.run([exe, "--raw", prefix + ".seq", prefix + ".model", "--repeat", "30", "--depth", depth], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "the same list every run: yes" in out.stdout and f"30 runs, {depth} in flight" in out.stdout and "GCUPS" in out.stdout
 
 
 def test_havac_benchmark_binary(tmp_path):

@@ -20,22 +20,30 @@ def main():
         d_seq = torch.from_numpy(packed).to(dev)
         d_phmm = torch.from_numpy(model.reshape(-1)).to(dev)
         cap = max(1 << 20, int(ncols * rows * 4e-5))
-        for depth in (1, 2):
+        # the bare context on a stream of the caller's (no pipe): what the pipe's bookkeeping adds to a strictly serial step
+        from havac_amd.ssv import SsvContext
+        ctx = SsvContext()
+        hits = torch.zeros(cap, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(dev)
+        for name, stream in (("torch's current (null) stream", torch.cuda.current_stream(dev).cuda_stream), ("a stream of its own", side.cuda_stream)):
+            for _ in range(20):
+                ctx.enqueue(d_seq.data_ptr(), ncols, d_phmm.data_ptr(), rows, hits.data_ptr(), hits.numel(), 0, 1, 0, stream)
+                found = ctx.finish()
+            t0 = time.perf_counter()
+            for _ in range(60):
+                ctx.enqueue(d_seq.data_ptr(), ncols, d_phmm.data_ptr(), rows, hits.data_ptr(), hits.numel(), 0, 1, 0, stream)
+                found = ctx.finish()
+            step = (time.perf_counter() - t0) / 60 * 1e3
+            print(f"rows {rows} bare context on {name}: found {found} step {step:.4f} ms = {ncols * rows / step / 1e9:.2f} TCUPS", flush=True)
+        ctx.close()
+        del hits
+        for depth, early in ((1, 0), (2, 0)):
             eng = ShardedSsv(cap, dev, depth=depth)
-            def run(n):
-                res, ms = None, []
-                for _ in range(n):
-                    eng.submit(d_seq, ncols, d_phmm, rows)
-                    if len(eng.in_flight) == len(eng.slots):
-                        res = eng.collect(); ms.append(eng.ctx.last_ms())
-                while eng.in_flight:
-                    res = eng.collect(); ms.append(eng.ctx.last_ms())
-                return res, ms
-            run(20)
+            eng.run_many(20, d_seq, ncols, d_phmm, rows)
             torch.cuda.synchronize(dev)
             n = 60
             t0 = time.perf_counter()
-            (recs, found), ms = run(n)
+            (recs, found), ms = eng.run_many(n, d_seq, ncols, d_phmm, rows, inputs_ready=True)
             torch.cuda.synchronize(dev)
             step = (time.perf_counter() - t0) / n * 1e3
             k = sum(m[0] for m in ms) / len(ms)
