@@ -12,14 +12,16 @@ is already resident in HBM: model padding copy + SSV kernel + hit compaction +
 ordering of the hit records into the reference's device order (+ for N > 1 the
 RCCL gather of the records to rank 0, where the rank lists concatenate to the
 ordered whole).  Two passes are in flight (--pipeline-depth), each with its own
-context and hit buffer: while the host waits for the hit count of pass k, orders its records and gathers
-them (on the pass's own low-priority stream), the SSV kernel of pass k+1 runs; the SSV kernels of consecutive
-passes (of 4e10 cells and more) alternate between two high-priority streams, so that a kernel starts while its predecessor drains (a launch's
-last, half-empty round of tiles and the gap between two dependent launches are filled by its neighbour: a step then
-takes LESS than one kernel alone).  All K passes are complete when the timed region ends.  `kernel.avg_ms` and
-`roofline` are the kernel ALONE: HIP events around the launch in the same K passes run strictly one after the other
-(`config.ms_per_step_strictly_serial`), where nothing shares the chip with it; `kernel.avg_ms_overlapped` is what the
-same events read inside the timed region.
+context and hit buffer, and each -- from its first kernel to the ordering of its records -- on one of two high-priority
+streams that consecutive passes alternate between: while the host waits for pass k and its records are ordered and
+gathered, the SSV kernel of pass k+1 runs, and has started while kernel k was draining (a launch's last, half-empty round
+of tiles and the gap between two dependent launches are filled by its neighbour: a step then takes LESS than one kernel
+alone).  The engine is libhavac_dev.so's pipe (include/havac_dev.h level 2b); the timed region runs inside havac_pipe_run, no
+Python between two passes: what is measured is what a C++ caller of the library gets (havac_benchmark --raw --repeat measures
+the same through the handle API, without Python in the process).  All K passes are complete when the timed region ends.
+`kernel.avg_ms` and `roofline` are the kernel ALONE: HIP events around the launch in the same K passes run strictly one after
+the other (`config.ms_per_step_strictly_serial`, the figure of the reference's one-run-at-a-time API), where nothing shares the
+chip with it; `kernel.avg_ms_overlapped` is what the same events read inside the timed region.
 
 Workloads (BASELINE.json configs):
   c2 (default)  one pHMM of L = 1024 rows x 100 Mbp (100,012,032 columns after padding to 12288) per GPU; N > 1 is
@@ -454,15 +456,15 @@ def main():
     ap.add_argument("--columns-per-gpu", type=int, default=0, help="probe: this many columns (a multiple of 12288) per unit")
     ap.add_argument("--pipeline-depth", type=int, default=0,
                     help="passes in flight (own context, hit buffer and stream each): the ordering / gather of pass k "
-                         "overlaps the SSV kernel of pass k+1, which (passes of 4e10 cells and more) starts on a second kernel "
-                         "stream while kernel k drains.  1 = strictly serial; 0 = 2 (N > 1: the gather hides behind the next "
+                         "overlaps the SSV kernel of pass k+1, which starts on the other of two streams "
+                         "while kernel k drains.  1 = strictly serial; 0 = 2 (N > 1: the gather hides behind the next "
                          "kernel), 1 above 1e14 cells on one GPU")
     ap.add_argument("--tuning", default="", help="experiments: rows_per_block,tiles_per_item,block_tails,ordering[,parts_log2,"
                     "split_rounds_x4,short_rows,guide] for havac_ssv_set_tuning / havac_ssv_set_split_tuning (-1 = the library's own "
                     "rule), e.g. --tuning=-1,-1,-1,0 orders with the radix sort")
     ap.add_argument("--kernel-streams", type=int, default=0, choices=(0, 1, 2),
-                    help="streams the SSV kernels of consecutive passes alternate between: 0 = the library's rule (two from 4e10 cells per "
-                         "shard on), 1 = back to back, 2 = side by side")
+                    help="streams consecutive passes alternate between (a pass -- preparation, SSV kernel, ordering -- is one stream's "
+                         "business): 0 = the library's rule (two where passes are in flight), 1 = every pass on one stream, 2")
     ap.add_argument("--backend", default=os.environ.get("HAVAC_BENCH_BACKEND", "nccl"), choices=("nccl", "gloo"),
                     help="torch.distributed backend of an N > 1 run: nccl (= RCCL, one rank per GPU: what the driver runs) or gloo (a "
                          "rehearsal with several ranks on ONE GPU, which RCCL refuses)")
@@ -552,7 +554,7 @@ def main():
     hit_capacity = max(1 << 20, int(my_cells * (4e-5 if my_cells <= 1e13 else 1.2e-5)))
     # kernels of consecutive passes side by side (two kernel streams) where a pass is long enough to gain from it (512 rows x
     # 100 Mbp, 5.1e10 cells: +1.8 %; 1024 rows: +3.5 %; 256 rows, 2.6e10 cells, the resident-table kernel: -4 %)
-    # (the rule itself lives in ShardedSsv; --kernel-streams 1 / 2 force one or the other)
+    # (the rule itself lives in libhavac_dev.so's pipe; --kernel-streams 1 / 2 force one or the other)
     kernel_streams = args.kernel_streams or None
     # passes in flight: 2 where kernels overlap -- the next pass's kernel starts (on the second kernel stream) while this one
     # drains, the host's wait, the ordering and for N > 1 the gather (C4: 36 GB to rank 0 per pass) hide behind it; a third
@@ -700,7 +702,7 @@ def main():
                 "rows": nrows, "columns": ncols, "columns_per_gpu": cols_per_gpu, "cells_per_step": total_cells,
                 "hits_per_step": nhits, "planted_homologs": planted, "passes_in_flight": depth, "kernel_streams": kernel_streams,
                 "overlap": (None if kernel_streams < 2 else
-                            "consecutive passes' SSV kernels run on two streams: kernel k+1 starts while kernel k drains, so ms_per_step can be "
+                            "consecutive passes run on two streams (a pass -- preparation, SSV kernel, ordering -- on one of them): kernel k+1 starts while kernel k drains and runs beside the ordering of pass k, so ms_per_step can be "
                             "BELOW kernel.avg_ms (the kernel alone, from the strictly serial passes); every one of the K passes is complete "
                             "inside the timed region, and each pass's hit list is checked as before"),
                 "ms_per_step_strictly_serial": None if serial_ms is None else round(serial_ms, 4),

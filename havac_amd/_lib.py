@@ -74,7 +74,6 @@ SIGNATURES = {
     "havac_ssv_shard_cells": (C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
     "havac_ssv_shard_columns": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32,
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-    "havac_ssv_set_early_preparation": (C.c_int, [_vp, C.c_int]),
     "havac_ssv_query": (C.c_int, [_vp]),
     "havac_ssv_wait_inputs": (C.c_int, [_vp, C.c_int]),
     "havac_pipe_create": (C.c_int, [C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),

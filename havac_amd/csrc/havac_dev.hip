@@ -343,8 +343,7 @@ struct havac_ssv_ctx {
     int tune_ordering = -1;                    // -1 / 1: bucket ordering, 0: always the radix sort (experiments, tests)
     uint32_t last_order_buckets = 0, last_order_largest = 0; int last_order_path = 0;   // what the last pass's ordering did (tests, tools)
     unsigned long long* d_count = nullptr;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pass start, kernel start, kernel end, records ordered, model prepared
-    bool prepare_early = false;                // havac_ssv_set_early_preparation: the pass's first kernel runs on the ordering stream
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // pass start, kernel start (the model is prepared), kernel end, records ordered
     CellRecord* trace_cells = nullptr; uint32_t trace_row0 = 0, trace_rows = 0, trace_cols = 0; uint64_t trace_col0 = 0;   // per-cell trace window (debugging)
     hipStream_t order_stream = nullptr;        // optional: where finish() orders the records (default: the enqueue's stream)
     uint64_t window_first = 0, window_columns = 0;   // the caller's sequence buffer holds only these columns (0, 0: all of them)
@@ -457,13 +456,6 @@ extern "C" int havac_ssv_set_order_stream(havac_ssv_ctx* c, void* hip_stream) {
     if (!c) return HAVAC_E_ARGUMENT;
     if (c->pending) { c->err = "a pass is in flight: set the ordering stream between passes"; return HAVAC_E_LOGIC; }
     c->order_stream = (hipStream_t)hip_stream;
-    return HAVAC_OK;
-}
-
-extern "C" int havac_ssv_set_early_preparation(havac_ssv_ctx* c, int on) {
-    if (!c) return HAVAC_E_ARGUMENT;
-    if (c->pending) { c->err = "a pass is in flight: change this between passes"; return HAVAC_E_LOGIC; }
-    c->prepare_early = on != 0;
     return HAVAC_OK;
 }
 
@@ -711,29 +703,21 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         if (int rc2 = ensure_alt(c, std::min<uint64_t>(hit_capacity, 1ull << 22), stream)) return rc2;
         if (int rc2 = ensure_buckets(c, 1u << 16, stream)) return rc2;
     }
-    // The pass's first kernel (the padded model, the chunk flags, the cleared counters) normally runs in front of the SSV kernel, on
-    // its stream.  Where passes run beside each other it may run EARLY instead, on this context's ordering stream, which is idle
-    // when a pass is enqueued: the kernel stream then holds nothing but SSV kernels, back to back -- one dependent launch
-    // between two of them instead of two and a 4 us kernel (havac_ssv_set_early_preparation; the caller has made the ordering
-    // stream wait for the inputs).
-    const hipStream_t prep = (c->prepare_early && c->order_stream) ? c->order_stream : stream;
     if (c->order_dirty && c->bucket_counts) {     // an earlier ordering was cut short: its counts cannot be trusted
-        HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, c->bucket_alloc * sizeof(uint32_t), prep));
+        HIP_TRY(c->err, hipMemsetAsync(c->bucket_counts, 0, c->bucket_alloc * sizeof(uint32_t), stream));
         c->order_dirty = false;
     }
 
-    HIP_TRY(c->err, hipEventRecord(c->ev[0], prep));
+    HIP_TRY(c->err, hipEventRecord(c->ev[0], stream));
     // one launch: the padded copy of the model, the chunk flags, and everything the pass's kernels count in, cleared -- the hit
     // counter, the tickets, the tails' sums, the ordering's barrier words, the hand-off counts of cut tiles.  (Separator pairs
     // score -128 twice in a row whatever the model says: with a mask there are no flags, every chunk tests every two steps.)
     {
         const uint32_t nflagwords = c->pair_mask ? 0u : flag_words;
         const uint32_t threads = std::max(std::max(model_words, nflagwords * 32u), kControlWords);
-        hipLaunchKernelGGL(ssv_prepare_model, dim3((threads + 255) / 256), dim3(256), 0, prep, d_phmm, nrows, c->rows8, model_words,
+        hipLaunchKernelGGL(ssv_prepare_model, dim3((threads + 255) / 256), dim3(256), 0, stream, d_phmm, nrows, c->rows8, model_words,
                            t.nrows_padded, c->chunk_flags, nflagwords, c->d_count, c->control, kControlWords, c->block_flags, (uint32_t)handoff_words);
     }
-    HIP_TRY(c->err, hipEventRecord(c->ev[4], prep));
-    if (prep != stream) HIP_TRY(c->err, hipStreamWaitEvent(stream, c->ev[4], 0));
     HIP_TRY(c->err, hipEventRecord(c->ev[1], stream));
     if (te > tb) {
         SsvRare& R = L;
@@ -972,7 +956,7 @@ extern "C" int havac_ssv_wait_inputs(havac_ssv_ctx* c, int sequence_too) {
     if (!c) return HAVAC_E_ARGUMENT;
     if (!c->pending) return HAVAC_OK;                      // nothing enqueued reads anything
     HIP_TRY(c->err, hipSetDevice(c->device));
-    HIP_TRY(c->err, hipEventSynchronize(c->ev[sequence_too ? 2 : 4]));
+    HIP_TRY(c->err, hipEventSynchronize(c->ev[sequence_too ? 2 : 1]));
     return HAVAC_OK;
 }
 

@@ -3,9 +3,12 @@
 // The reference runs one pass at a time: invokeHavacSsvAsync, waitForHavacSsvAsync, getHitList (host/HavacHwClient.cpp:141-157,
 // 172-202).  On an MI355X a pass of C2 is 1.85 ms of kernel and ~0.08 ms of everything else (the preparation in front of the
 // kernel, the ordering of the records behind it, the host's turnaround), and a kernel's last round of tiles leaves the chip
-// half empty: with TWO passes in flight -- each with its own context, hit buffer and low-priority ordering stream, the SSV
-// kernels of consecutive passes alternating between two high-priority streams -- the ordering, the gather (N > 1) and the
-// host's work of pass k run beside the kernel of pass k + 1, which itself starts while kernel k drains.  Rounds 1-4 had this
+// half empty: with TWO passes in flight -- each with its own context and hit buffer, consecutive passes alternating between two
+// high-priority streams, a whole pass (preparation, SSV kernel, ordering) on ONE of them -- the ordering, the gather (N > 1) and
+// the host's work of pass k run beside the kernel of pass k + 1, which itself starts while kernel k drains.  (Rounds 3-4 gave every
+// slot a low-priority stream for its ordering, beside ONE kernel stream for short passes: with a pass's launches down from ten
+// to eight and no host round trip inside it, two plain streams are faster at every model height -- 64 rows x 100 Mbp 38.4 ->
+// 42.2 TCUPS, 256 rows 50.3 -> 53.9, 512 rows 53.0 -> 56.1, C2 unchanged: profiles/r05n_*.)  Rounds 1-4 had this
 // engine in Python over torch streams (havac_amd/dist.py: ShardedSsv); a C++ caller of the drop-in API got the strictly serial
 // figure.  Since round 5 a pass is enqueued whole (three launches for the kernel, five for the ordering, no
 // host round trip: havac_dev.hip, hit_order.hip.h), so the engine is a few lines of stream bookkeeping -- here, in C++, used
@@ -22,16 +25,11 @@
 
 namespace {
 
-constexpr double kTwoStreamsFromCells = 4e10;      // per shard: from here on consecutive passes' kernels run side by side
-#ifndef HAVAC_EARLY_PREPARATION
-#define HAVAC_EARLY_PREPARATION 0      // measured (tools/step_probe.py, one box, two rounds each): 64 rows 0.204-0.212 ms per step against 0.192-0.194,
-#endif                                 // 256 rows 0.531-0.534 against 0.525, C2 1.788-1.816 against 1.805-1.807: the low-priority stream starts it late
-constexpr bool kEarlyPreparation = HAVAC_EARLY_PREPARATION != 0;      // a pass's first kernel on its slot's ordering stream (havac_ssv_set_early_preparation)
 
 struct Slot {
     havac_ssv_ctx* ctx = nullptr;
     uint64_t* d_hits = nullptr;
-    hipStream_t order_stream = nullptr;        // depth > 1: the slot's own low-priority stream (ordering, gather)
+    hipStream_t stream = nullptr;              // the stream the slot's pass in flight was submitted on
     uint64_t* merged = nullptr; uint64_t merged_capacity = 0;      // rank 0 of a sharded run: the gather's receive buffer
     hipEvent_t gathered = nullptr;             // behind the slot's last gather: its hit buffer may be written again
     hipEvent_t g0 = nullptr, g1 = nullptr;     // timing of the slot's last gather
@@ -44,7 +42,7 @@ struct havac_pipe {
     int device = 0;
     uint32_t depth = 1;
     uint64_t hit_capacity = 0;
-    int kernel_streams = -1;                   // -1: the library's rule per pass, 1, 2
+    int kernel_streams = 1;                    // 1: every pass on one stream; 2: consecutive passes alternate between two
     hipStream_t kstream[2] = {nullptr, nullptr};
     int flip = 0;
     bool used_two_streams = false;
@@ -79,12 +77,10 @@ extern "C" void havac_pipe_destroy(havac_pipe* p) {
     (void)hipSetDevice(p->device);
     for (int k = 0; k < 2; k++) if (p->kstream[k]) (void)hipStreamSynchronize(p->kstream[k]);
     for (Slot& s : p->slots) {
-        if (s.order_stream) (void)hipStreamSynchronize(s.order_stream);
         free_slot(s, nullptr);
         if (s.gathered) (void)hipEventDestroy(s.gathered);
         if (s.g0) (void)hipEventDestroy(s.g0);
         if (s.g1) (void)hipEventDestroy(s.g1);
-        if (s.order_stream) (void)hipStreamDestroy(s.order_stream);
     }
     if (p->inputs) (void)hipEventDestroy(p->inputs);
     for (int k = 0; k < 2; k++) if (p->kstream[k]) (void)hipStreamDestroy(p->kstream[k]);
@@ -98,28 +94,24 @@ extern "C" int havac_pipe_create(uint32_t depth, uint64_t hit_capacity, int kern
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return HAVAC_E_NO_DEVICE;
     havac_pipe* p = new (std::nothrow) havac_pipe;
     if (!p) return HAVAC_E_NOMEM;
-    p->depth = depth; p->hit_capacity = hit_capacity; p->kernel_streams = kernel_streams < 0 ? -1 : kernel_streams;
+    p->depth = depth; p->hit_capacity = hit_capacity;
+    p->kernel_streams = kernel_streams < 0 ? (depth > 1 ? 2 : 1) : (depth > 1 ? kernel_streams : 1);
     auto body = [&]() -> int {
         PIPE_HIP(p, hipGetDevice(&p->device));
         int least = 0, greatest = 0;
         PIPE_HIP(p, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        // The SSV kernels: high priority.  Two streams where kernels of consecutive passes may run side by side -- a kernel then
-        // starts while its predecessor drains: the last, half-empty round of a launch's tiles and the gap between two dependent
-        // launches are filled by its neighbour's first workgroups (C2: 1.878 -> 1.82 ms per step, less than one kernel takes alone)
+        // High priority.  Two streams where passes are in flight: a pass -- its preparation, its SSV kernel, the ordering of its
+        // records -- is one stream's business, consecutive passes alternate, so a kernel starts while its predecessor drains (the
+        // last, half-empty round of a launch's tiles and the ~16 us between two dependent launches are filled by its neighbour's
+        // first workgroups: C2 1.878 -> 1.78 ms per step, less than one kernel takes alone) and runs beside its predecessor's ordering
         PIPE_HIP(p, hipStreamCreateWithPriority(&p->kstream[0], hipStreamNonBlocking, greatest));
-        if (depth > 1 && p->kernel_streams != 1) PIPE_HIP(p, hipStreamCreateWithPriority(&p->kstream[1], hipStreamNonBlocking, greatest));
+        if (p->kernel_streams == 2) PIPE_HIP(p, hipStreamCreateWithPriority(&p->kstream[1], hipStreamNonBlocking, greatest));
+        (void)least;
         PIPE_HIP(p, hipEventCreateWithFlags(&p->inputs, hipEventDisableTiming));
         p->slots.resize(depth);
         for (Slot& s : p->slots) {
             if (havac_ssv_ctx_create(&s.ctx) != HAVAC_OK) { p->err = "could not create an SSV context"; return HAVAC_E_RUNTIME; }
             if (hit_capacity) PIPE_HIP(p, hipMalloc(&s.d_hits, hit_capacity * sizeof(uint64_t)));
-            if (depth > 1) {
-                // the slot's own stream: the ordering of its records and their gather (low priority: what it runs fills the gaps
-                // the SSV kernels leave, it does not compete with them for compute units)
-                PIPE_HIP(p, hipStreamCreateWithPriority(&s.order_stream, hipStreamNonBlocking, least));
-                if (int rc = havac_ssv_set_order_stream(s.ctx, s.order_stream)) { p->err = havac_ssv_ctx_last_error(s.ctx); return rc; }
-                if (kEarlyPreparation) (void)havac_ssv_set_early_preparation(s.ctx, 1);
-            }
             PIPE_HIP(p, hipEventCreateWithFlags(&s.gathered, hipEventDisableTiming));
             PIPE_HIP(p, hipEventCreate(&s.g0));
             PIPE_HIP(p, hipEventCreate(&s.g1));
@@ -160,18 +152,17 @@ extern "C" int havac_pipe_submit(havac_pipe* p, const uint8_t* d_sequence, uint6
     PIPE_HIP(p, hipSetDevice(p->device));
     Slot& s = p->slots[p->next];
     hipStream_t stream = p->kstream[0];
-    if (p->kstream[1] && (p->kernel_streams == 2 ||
-                          (double)havac_ssv_shard_cells(nsymbols, nrows, shard_index, shard_count) >= kTwoStreamsFromCells)) {
+    if (p->kstream[1]) {
         p->used_two_streams = true;
         p->flip ^= 1;
         stream = p->kstream[p->flip];
     }
+    s.stream = stream;
     // the caller's inputs (HAVAC_NO_STREAM: they are in place, nothing to wait for -- an event on the legacy null stream alone
     // costs a strictly serial 0.2 ms pass 5 %); and, in a sharded run, the slot's last gather, which reads the hit buffer this pass writes
     if (caller_stream != HAVAC_NO_STREAM) {
         PIPE_HIP(p, hipEventRecord(p->inputs, (hipStream_t)caller_stream));
         PIPE_HIP(p, hipStreamWaitEvent(stream, p->inputs, 0));
-        if (s.order_stream && kEarlyPreparation) PIPE_HIP(p, hipStreamWaitEvent(s.order_stream, p->inputs, 0));      // the pass's first kernel runs there
     }
     if (p->gather) PIPE_HIP(p, hipStreamWaitEvent(stream, s.gathered, 0));
     const int rc = havac_ssv_enqueue(s.ctx, d_sequence, nsymbols, d_phmm, nrows, shard_index, shard_count, s.d_hits, p->hit_capacity, d_abort_flag, stream);
@@ -227,7 +218,7 @@ extern "C" int havac_pipe_collect(havac_pipe* p, uint64_t* found_out, const uint
     // A sharded run: the count exchange still runs on every rank when this rank's pass failed (-1), and every rank returns an
     // error afterwards, so no rank is left waiting inside a collective.
     if (caller_stream == HAVAC_NO_STREAM) caller_stream = nullptr;
-    const hipStream_t stream = s.order_stream ? s.order_stream : (hipStream_t)caller_stream;
+    const hipStream_t stream = s.stream ? s.stream : (hipStream_t)caller_stream;      // (idle: the pass has been waited for; the next pass of this slot queues behind)
     harvest(p, s);
     PIPE_HIP(p, hipEventRecord(s.g0, stream));
     std::vector<int64_t> counts(p->world, 0);
@@ -320,7 +311,6 @@ extern "C" int havac_pipe_release(havac_pipe* p) {
     PIPE_HIP(p, hipSetDevice(p->device));
     for (int k = 0; k < 2; k++) if (p->kstream[k]) PIPE_HIP(p, hipStreamSynchronize(p->kstream[k]));
     for (Slot& s : p->slots) {
-        if (s.order_stream) PIPE_HIP(p, hipStreamSynchronize(s.order_stream));
         harvest(p, s);
         free_slot(s, p->last_records);
     }

@@ -298,9 +298,10 @@ class ShardedSsv:
     C++ since round 5, so that a C++ caller of the drop-in API gets the same engine (havac_dev_set_pipeline_depth).
     depth > 1 keeps that many passes in flight: ``submit`` enqueues a whole pass, ``collect`` finishes the oldest one.  While
     the host waits for pass k and its records are ordered and (N > 1) gathered over RCCL, the SSV kernel of pass k+1 is
-    already running; the kernels of consecutive passes alternate between two high-priority streams where passes are long
-    enough to gain from it (kernel_streams: None = the library's rule, two from 4e10 cells per shard on; 1; 2).  A kernel's
-    event-timed duration then includes what its neighbours took of the chip meanwhile; a depth-1 engine measures a kernel alone.
+    already running: a pass -- preparation, SSV kernel, ordering -- is the business of ONE of two high-priority streams, and
+    consecutive passes alternate between them (kernel_streams: None = that; 1 = every pass on one stream, experiments).  A
+    kernel's event-timed duration then includes what its neighbours took of the chip meanwhile; a depth-1 engine measures a
+    kernel alone.
 
     The records ``collect`` returns live in libhavac_dev.so's buffers (the slot's hit buffer, or rank 0's receive buffer):
     they are valid until that slot is submitted again, and the caller's current stream has been made to wait for them.

@@ -265,12 +265,6 @@ int havac_ssv_set_separator_mask(havac_ssv_ctx *ctx, const uint8_t *d_pair_bitma
  * No counterpart in the reference (one run at a time, host/HavacHwClient.cpp:150-170). */
 int havac_ssv_set_order_stream(havac_ssv_ctx *ctx, void *hip_stream);
 
-/* Optional, for callers that keep passes in flight with an ordering stream set: the pass's first kernel (the padded copy of the
- * model, the cleared counters) runs on the ORDERING stream, as soon as that stream's earlier work is done, instead of on the
- * enqueue's stream in front of the SSV kernel -- the enqueue's stream then carries nothing but SSV kernels, back to back.  The
- * caller must have made the ordering stream wait for the inputs (d_phmm) itself; havac_pipe_submit does. */
-int havac_ssv_set_early_preparation(havac_ssv_ctx *ctx, int on);
-
 /* Per-cell trace: the counterpart of the reference's HAVAC_PER_CELL_DATA_TESTING build (device/PublicDefines.h:11,
  * device/HavacHls.cpp:388-399: every cell processor records prevValue, matchScore, cellValue, symbol, passesThreshold;
  * test/byCellComparator/byCellComparator.cpp:47-96 compares them with softSsv's).  While a trace window is set, passes
@@ -416,11 +410,11 @@ const char *havac_ssv_ctx_last_error(havac_ssv_ctx *ctx);
  * Level 2b: passes in flight
  * ---------------------------------------------------------------------- */
 /* No counterpart in the reference, whose API is one run at a time (host/HavacHwClient.cpp:141-157: invoke, wait, list).  A pipe
- * keeps up to `depth` passes in flight on the device that is current when it is created, each in a slot of its own -- a context,
- * a hit buffer of hit_capacity records, a low-priority stream for the ordering of its records and (sharded runs) their gather --
- * with the SSV kernels of consecutive passes on one high-priority stream, or alternating between two (kernel_streams: 1, 2, or -1
- * = the library's rule per pass: two from 4e10 cells per shard on): while the host waits for pass k, its records are ordered and
- * gathered, the kernel of pass k + 1 runs -- and has started while kernel k was draining.  depth 1 is the reference's behaviour.
+ * keeps up to `depth` passes in flight on the device that is current when it is created, each in a slot of its own -- a context
+ * and a hit buffer of hit_capacity records -- and each, from its first kernel to the ordering of its records, on ONE of two
+ * high-priority streams that consecutive passes alternate between (kernel_streams: -1 = that; 1 = every pass on the same stream;
+ * 2): while the host waits for pass k and its records are ordered and gathered, the kernel of pass k + 1 runs -- and has started
+ * while kernel k was draining.  depth 1 is the reference's behaviour.
  *
  *   havac_pipe_submit   enqueues one whole pass (as havac_ssv_enqueue; all pointers are DEVICE pointers the caller keeps alive)
  *                       behind what `caller_stream` holds now (the inputs' producer; HAVAC_NO_STREAM: nothing to wait for);

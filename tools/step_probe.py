@@ -37,8 +37,8 @@ def main():
             print(f"rows {rows} bare context on {name}: found {found} step {step:.4f} ms = {ncols * rows / step / 1e9:.2f} TCUPS", flush=True)
         ctx.close()
         del hits
-        for depth, early in ((1, 0), (2, 0)):
-            eng = ShardedSsv(cap, dev, depth=depth)
+        for depth, streams in ((1, None), (2, 1), (2, 2), (3, 1), (3, 2)):
+            eng = ShardedSsv(cap, dev, depth=depth, kernel_streams=streams)
             eng.run_many(20, d_seq, ncols, d_phmm, rows)
             torch.cuda.synchronize(dev)
             n = 60
@@ -48,7 +48,7 @@ def main():
             step = (time.perf_counter() - t0) / n * 1e3
             k = sum(m[0] for m in ms) / len(ms)
             tot = sum(m[1] for m in ms) / len(ms)
-            print(f"rows {rows} depth {depth}: found {found} step {step:.4f} ms = {ncols * rows / step / 1e9:.2f} TCUPS; kernel {k:.4f} ms, enqueue-to-ordered {tot:.4f} ms", flush=True)
+            print(f"rows {rows} depth {depth} kernel streams {streams}: found {found} step {step:.4f} ms = {ncols * rows / step / 1e9:.2f} TCUPS; kernel {k:.4f} ms, enqueue-to-ordered {tot:.4f} ms", flush=True)
             eng.release()
 
 
