@@ -11,7 +11,7 @@ A step is one whole pass of the hot path over one batch of synthetic input that
 is already resident in HBM: model padding copy + SSV kernel + hit compaction +
 ordering of the hit records into the reference's device order (+ for N > 1 the
 RCCL gather of the records to rank 0, where the rank lists concatenate to the
-ordered whole).  Two passes are in flight (--pipeline-depth), each with its own
+ordered whole).  Three passes are in flight (--pipeline-depth), each with its own
 context and hit buffer, and each -- from its first kernel to the ordering of its records -- on one of two high-priority
 streams that consecutive passes alternate between: while the host waits for pass k and its records are ordered and
 gathered, the SSV kernel of pass k+1 runs, and has started while kernel k was draining (a launch's last, half-empty round
@@ -76,7 +76,7 @@ WORKLOADS = {
     # (the GPU needs ~10 launches of 2 ms to reach its clock under this load -- the kernel's duration falls from 2.11 to 1.83 ms
     # over the first ten launches of a run, profiles/r02b_kernel_stats_c2.csv; bench.py runs its own clock warm-up in front
     # of the --warmup passes and reports how many passes that took: `clock_warmup_passes`)
-    "c2": dict(rows=1024, real=100_000_000, scaling="weak", steps=50, warmup=5,
+    "c2": dict(rows=1024, real=100_000_000, scaling="weak", steps=100, warmup=5,
                label="C2: 1 pHMM L=1024 x 100 Mbp (100,012,032 columns padded to 12288) per GPU"),
     "c3": dict(rows=None, real=10_000_000, scaling="weak", steps=10, warmup=2,
                label="C3: 1000-model collection (L 50-2000, 503,329 rows concatenated) x 10 Mbp (10,002,432 columns) per GPU"),
@@ -457,8 +457,8 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=0,
                     help="passes in flight (own context, hit buffer and stream each): the ordering / gather of pass k "
                          "overlaps the SSV kernel of pass k+1, which starts on the other of two streams "
-                         "while kernel k drains.  1 = strictly serial; 0 = 2 (N > 1: the gather hides behind the next "
-                         "kernel), 1 above 1e14 cells on one GPU")
+                         "while kernel k drains.  1 = strictly serial; 0 = 3 (the third is slack for a host that wakes late from "
+                         "its wait; 2 for C4 on several GPUs), 1 above 1e14 cells on one GPU")
     ap.add_argument("--tuning", default="", help="experiments: rows_per_block,tiles_per_item,block_tails,ordering[,parts_log2,"
                     "split_rounds_x4,short_rows,guide] for havac_ssv_set_tuning / havac_ssv_set_split_tuning (-1 = the library's own "
                     "rule), e.g. --tuning=-1,-1,-1,0 orders with the radix sort")
@@ -556,16 +556,18 @@ def main():
     # 100 Mbp, 5.1e10 cells: +1.8 %; 1024 rows: +3.5 %; 256 rows, 2.6e10 cells, the resident-table kernel: -4 %)
     # (the rule itself lives in libhavac_dev.so's pipe; --kernel-streams 1 / 2 force one or the other)
     kernel_streams = args.kernel_streams or None
-    # passes in flight: 2 where kernels overlap -- the next pass's kernel starts (on the second kernel stream) while this one
-    # drains, the host's wait, the ordering and for N > 1 the gather (C4: 36 GB to rank 0 per pass) hide behind it; a third
-    # pass in flight only adds a third kernel's preparation and ordering to the mix (C2: 1.819-1.821 ms per step with two,
-    # 1.831-1.844 with three, 1.889 with four, one box; short passes on one kernel stream likewise: 64 rows x 100 Mbp 0.175 ms
-    # per step with two, 0.200 with three; 256 rows 0.507 against 0.530); 1 above 1e14 cells on one GPU (C4 on one card: 93 GB
-    # of hit and ordering buffers per pass in flight)
+    # passes in flight: 3 -- the next pass's kernel starts (on the other of two streams) while this one drains, and the host's
+    # wait, the ordering and for N > 1 the gather (C4: 36 GB to rank 0 per pass) hide behind it.  Two are enough for that on a quiet
+    # host (C2 57.25-57.27 TCUPS with two, 57.27-57.31 with three; short passes gain from the third: 64 rows 43.7 -> 44.4, 32 rows
+    # 32.7 -> 37.1: profiles/r05n_*); the third is slack for a host that wakes late from its wait for pass k -- on a box whose
+    # CPUs were busy a two-deep run lost 10 % to that (profiles/r05o_bench_c2_busy_host.json).  1 above 1e14 cells on one GPU (C4
+    # on one card: 93 GB of hit and ordering buffers per pass in flight)
     if args.pipeline_depth > 0:
         depth = args.pipeline_depth
     else:
-        depth = 2 if world > 1 or my_cells <= 1e14 else 1
+        depth = 3 if world > 1 or my_cells <= 1e14 else 1
+        if world > 1 and total_cells > 1e14:      # (C4: rank 0 holds a 36 GB receive buffer per pass in flight)
+            depth = 2
     tuning = [int(v) for v in args.tuning.split(",")] if args.tuning else None
     engine = ShardedSsv(hit_capacity, device, depth=depth, gather_when_alone=use_dist, tuning=tuning, kernel_streams=kernel_streams)
     if world > 1:

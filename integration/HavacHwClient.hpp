@@ -79,6 +79,11 @@ public:
         if (numHits) check(havac_dev_read_hits(dev, hitsAsU64.data(), numHits));
         return hitsAsU64;
     }
+    // ---- optional, no counterpart in the reference (one run at a time there): several runs open at once.  All the methods above
+    // then speak of the OLDEST open run; retire() closes it.  Unused, nothing changes for the reference's Havac.cpp.
+    void setPipelineDepth(uint32_t depth) { check(havac_dev_set_pipeline_depth(dev, depth)); }
+    void retire() { check(havac_dev_retire(dev)); }
+    uint32_t openRuns() { return havac_dev_open_runs(dev); }
 
 private:
     // C code -> the exception type host/HavacHwClient.cpp throws at the corresponding place (include/havac_dev.h

@@ -761,7 +761,7 @@ def test_bench_starts_its_own_ranks(world, rows, segments, gather):
     assert [p["rank"] for p in dd["per_rank"]] == list(range(world))
     assert dd["per_rank"][0]["halo_cells"] == 0 and all(p["halo_cells"] == (rows - 1) * rows // 2 for p in dd["per_rank"][1:])
     assert d["kernel"]["name"] == ("ssv_resident_kernel" if rows <= 256 else "ssv_diag_kernel")
-    assert d["config"]["passes_in_flight"] == 2 and d["config"]["kernel_streams"] == 2
+    assert d["config"]["passes_in_flight"] == 3 and d["config"]["kernel_streams"] == 2
     assert "strictly serial" in d["config"]["api_path"]
     assert sum(p["records"] for p in dd["per_rank"]) == d["config"]["hits_per_step"]
     assert all(p["kernel_ms"] > 0 for p in dd["per_rank"])
