@@ -1,5 +1,6 @@
 """Kernel time against model height (32-row chunks per tile) on 100 Mbp, with a model that cannot hit and with the
-Dfam-like one.   python tools/rows_probe.py [--tuning=a,b,...] [rows ...]     (tuning: ShardedSsv's, see bench.py --tuning)"""
+Dfam-like one.   python tools/rows_probe.py [--tuning=a,b,...] [--columns=N] [rows ...]     (tuning: ShardedSsv's, see bench.py --tuning;
+--columns: the sequence's length, rounded up to whole segments -- what a launch's start and end cost shows as the rate's dependence on N)"""
 import os
 import sys
 
@@ -13,13 +14,19 @@ from havac_amd.dist import ShardedSsv  # noqa: E402
 
 dev = torch.device("cuda", 0)
 ncols = 100_012_032
-packed = synth.random_packed(ncols, synth.SEED_SEQUENCE)
-d_seq = torch.from_numpy(packed).to(dev)
 args = sys.argv[1:]
 tuning = None
-if args and args[0].startswith("--tuning="):
-    tuning = [int(v) for v in args.pop(0)[len("--tuning="):].split(",")]
-eng = ShardedSsv(1 << 23, dev, tuning=tuning)
+while args and args[0].startswith("--"):
+    if args[0].startswith("--tuning="):
+        tuning = [int(v) for v in args.pop(0)[len("--tuning="):].split(",")]
+    elif args[0].startswith("--columns="):
+        ncols = -(-int(float(args.pop(0)[len("--columns="):])) // 12288) * 12288
+    else:
+        raise SystemExit(f"unknown option {args[0]}")
+packed = synth.random_packed(ncols, synth.SEED_SEQUENCE)
+d_seq = torch.from_numpy(packed).to(dev)
+eng = ShardedSsv(max(1 << 23, int(ncols * 1024 * 4e-5)), dev, tuning=tuning)
+print(f"{ncols} columns", flush=True)
 heights = [int(a) for a in args] or [32, 64, 96, 128, 160, 192, 256, 384, 512, 1024]
 for nrows in heights:
     out = []
