@@ -19,12 +19,17 @@ from oracle import pyoracle as O  # noqa: E402
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
+inflight = len(sys.argv) > 4 and sys.argv[4] == "inflight"
 rng = np.random.default_rng(seed)
 c = HavacHwClient()
+if inflight:
+    c.setPipelineDepth(2)
 bad = 0
 t0 = time.time()
 cells = hits_total = 0
-for case in range(cases):
+
+
+def make_case(case):
     nseg = int(rng.integers(1, 6))
     n = nseg * synth.SEGMENT
     nrows = int(rng.choice([1, 2, 3, 31, 32, 33, 64, 100, 255, 256, 257, 1000, 2048, 2049, 4100, int(rng.integers(1, 3000))]))
@@ -68,21 +73,17 @@ for case in range(cases):
     elif pick < 0.5:
         tuning[0] = int(rng.choice([1024, 2048, 4096, 8192]))
         tuning[4] = int(rng.choice([0, 3]))
-    c.setTuning(*tuning)
-    c.writeSequence(synth.pack_2bit(sym))
-    pieces = [(0, n)]
+    pieces, mask = [(0, n)], None
     if use_mask:
         seps = sorted(set((rng.integers(0, n // 2, size=int(rng.integers(1, 30))) * 2).tolist()))
         mask = np.zeros(n // 16, np.uint8)
         for s in seps:
             mask[s // 16] |= 1 << ((s // 2) % 8)
-        c.writeSeparatorMask(mask)
         pieces, start = [], 0
         for s in seps + [n]:
             if s > start:
                 pieces.append((start, s))
             start = s + 2
-    c.writePhmm(model)
     want = []
     for a, b in pieces:
         if big:
@@ -92,18 +93,44 @@ for case in range(cases):
         r, cc = O.unpack_hits(h)
         want.append(O.pack_hits(r, cc + np.uint64(a)))
     want = O.device_order(np.concatenate(want)) if want else np.zeros(0, np.uint64)
-    c.setHitCapacity(max(1 << 16, want.size + 8))
+    return dict(case=case, nseg=nseg, n=n, nrows=nrows, kind=kind, sym=sym, model=model, mask=mask, tuning=tuning, want=want)
+
+
+def start_run(k):
+    c.writeSequence(synth.pack_2bit(k["sym"]))
+    if k["mask"] is not None:
+        c.writeSeparatorMask(k["mask"])
+    c.writePhmm(k["model"])
     c.invokeHavacSsvAsync()
+
+
+def fetch_and_compare(k):
+    global bad, cells, hits_total
     state = c.waitForHavacSsvAsync()
     got = c.getHitList()
-    ok = state == 4 and np.array_equal(got, want)
-    cells += n * nrows
-    hits_total += want.size
+    if inflight:
+        c.retire()
+    ok = state == 4 and np.array_equal(got, k["want"])
+    cells += k["n"] * k["nrows"]
+    hits_total += k["want"].size
     if not ok:
         bad += 1
-        print(f"MISMATCH case {case}: nseg={nseg} nrows={nrows} kind={kind} mask={use_mask} tuning={tuning} got {got.size} want {want.size}", flush=True)
-    if case % (5 if big else 25) == (4 if big else 24):
-        print(f"{case + 1} cases, {bad} mismatches, {cells:.3g} cells, {hits_total} hits, {time.time() - t0:.0f} s", flush=True)
+        print(f"MISMATCH case {k['case']}: nseg={k['nseg']} nrows={k['nrows']} kind={k['kind']} mask={k['mask'] is not None} tuning={k['tuning']} "
+              f"got {got.size} want {k['want'].size}", flush=True)
+    if k["case"] % (5 if big else 25) == (4 if big else 24):
+        print(f"{k['case'] + 1} cases, {bad} mismatches, {cells:.3g} cells, {hits_total} hits, {time.time() - t0:.0f} s", flush=True)
+
+
+case = 0
+while case < cases:
+    group = [make_case(case + i) for i in range(2 if inflight and case + 1 < cases else 1)]
+    c.setTuning(*group[0]["tuning"])
+    c.setHitCapacity(max(1 << 16, max(k["want"].size for k in group) + 8))
+    for k in group:
+        start_run(k)          # (two runs open: the second's inputs are written while the first is in flight)
+    for k in group:
+        fetch_and_compare(k)
+    case += len(group)
 c.close()
-print(f"SOAK {'FAILED' if bad else 'OK'}: {cases} cases, seed {seed}, {bad} mismatches, {cells:.3g} cells, {hits_total} hits compared element for element")
+print(f"SOAK {'FAILED' if bad else 'OK'}: {cases} cases, seed {seed}{', two runs in flight' if inflight else ''}, {bad} mismatches, {cells:.3g} cells, {hits_total} hits compared element for element")
 sys.exit(1 if bad else 0)
