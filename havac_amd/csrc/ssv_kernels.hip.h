@@ -1322,10 +1322,8 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
     const uint32_t nchunks = nrows_padded / kChunkRows;
 
     // ---- the tables, once per workgroup: table c = chunk c's 16 step-pair tables (see build_tables in ssv_diag_body), table
-    // nchunks = the step behind the last chunk (its pair 0: the model's last row for the high cells, a padding row for the low).
-    // Called below, BEHIND the first loads of the wave's run: the first symbols and the abort word then travel while the tables are
-    // built -- a workgroup's start is one trip to memory long, not two in a row.
-    auto build_tables = [&]() {
+    // nchunks = the step behind the last chunk (its pair 0: the model's last row for the high cells, a padding row for the low)
+    {
         const uint32_t lane = fresh_lane();
         const uint32_t my_pair = lane >> 2, my_b = lane & 3;
         for (uint32_t c = wave; c <= nchunks; c += kWavesPerBlock) {
@@ -1338,7 +1336,8 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
             for (int a = 0; a < 4; a++) out[a] = u32x2{__builtin_amdgcn_perm(r0, r1, word_selector(a)), second};
             if (my_b == 0) *(lds_words_out_t)(uintptr_t)(at + kOutsideCode) = u32x2{kOutsideNeutral, kOutsideNeutral};
         }
-    };
+    }
+    __syncthreads();
 
     // ---- this wave's run of tiles
     uint32_t tile, tile_end;
@@ -1460,8 +1459,6 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
     const uint32_t tiles_mine = tile_end - tile;
 #endif
     if (tile < tile_end) issue_tile_loads(tile, ahead, true);
-    build_tables();
-    __syncthreads();
     for (; tile < tile_end; tile++) {
         if (!run_tile(tile, tile + 1 < tile_end ? 1u : 0u)) break;
     }
