@@ -462,9 +462,10 @@ def main():
     ap.add_argument("--tuning", default="", help="experiments: rows_per_block,tiles_per_item,block_tails,ordering[,parts_log2,"
                     "split_rounds_x4,short_rows,guide] for havac_ssv_set_tuning / havac_ssv_set_split_tuning (-1 = the library's own "
                     "rule), e.g. --tuning=-1,-1,-1,0 orders with the radix sort")
-    ap.add_argument("--kernel-streams", type=int, default=0, choices=(0, 1, 2),
-                    help="streams consecutive passes alternate between (a pass -- preparation, SSV kernel, ordering -- is one stream's "
-                         "business): 0 = the library's rule (two where passes are in flight), 1 = every pass on one stream, 2")
+    ap.add_argument("--kernel-streams", type=int, default=0, choices=(0, 1, 2, 3, 4),
+                    help="streams consecutive passes take in turn (a pass -- preparation, SSV kernel, ordering -- is one stream's "
+                         "business): 0 = the library's rule (two where passes are in flight), 1 = every pass on one stream, "
+                         "2 .. 4 = that many (three and four: experiments)")
     ap.add_argument("--backend", default=os.environ.get("HAVAC_BENCH_BACKEND", "nccl"), choices=("nccl", "gloo"),
                     help="torch.distributed backend of an N > 1 run: nccl (= RCCL, one rank per GPU: what the driver runs) or gloo (a "
                          "rehearsal with several ranks on ONE GPU, which RCCL refuses)")
@@ -643,7 +644,7 @@ def main():
     # engine is given back before anything else is allocated.  Rank 0 of `--gpus 8 --workload c4` holds 36 GB of records per receive buffer (DESIGN.md section 6
     # has the sum); the checks below allocate nothing of that size.
     engine_variant = engine.ctx.last_kernel_variant()
-    kernel_streams = 2 if engine.used_two_streams else 1      # (what the engine really used)
+    kernel_streams = engine.streams_used      # (what the engine really used)
     engine.release()
     if depth > 1:       # the same steps strictly one after the other, for the record (not `value`)
         serial = ShardedSsv(hit_capacity, device, depth=1, gather_when_alone=use_dist, tuning=tuning)
@@ -704,7 +705,7 @@ def main():
                 "rows": nrows, "columns": ncols, "columns_per_gpu": cols_per_gpu, "cells_per_step": total_cells,
                 "hits_per_step": nhits, "planted_homologs": planted, "passes_in_flight": depth, "kernel_streams": kernel_streams,
                 "overlap": (None if kernel_streams < 2 else
-                            "consecutive passes run on two streams (a pass -- preparation, SSV kernel, ordering -- on one of them): kernel k+1 starts while kernel k drains and runs beside the ordering of pass k, so ms_per_step can be "
+                            f"consecutive passes take {'two' if kernel_streams == 2 else kernel_streams} streams in turn (a pass -- preparation, SSV kernel, ordering -- on one of them): kernel k+1 starts while kernel k drains and runs beside the ordering of pass k, so ms_per_step can be "
                             "BELOW kernel.avg_ms (the kernel alone, from the strictly serial passes); every one of the K passes is complete "
                             "inside the timed region, and each pass's hit list is checked as before"),
                 "ms_per_step_strictly_serial": None if serial_ms is None else round(serial_ms, 4),

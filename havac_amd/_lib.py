@@ -87,6 +87,7 @@ SIGNATURES = {
     "havac_pipe_depth": (C.c_uint32, [_vp]),
     "havac_pipe_in_flight": (C.c_uint32, [_vp]),
     "havac_pipe_used_two_streams": (C.c_int, [_vp]),
+    "havac_pipe_streams_used": (C.c_int, [_vp]),
     "havac_pipe_context": (C.c_void_p, [_vp, C.c_int]),
     "havac_pipe_set_gather": (C.c_int, [_vp, _vp]),
     "havac_pipe_wait_gathers": (C.c_int, [_vp]),

@@ -42,9 +42,10 @@ struct havac_pipe {
     int device = 0;
     uint32_t depth = 1;
     uint64_t hit_capacity = 0;
-    int kernel_streams = 1;                    // 1: every pass on one stream; 2: consecutive passes alternate between two
-    hipStream_t kstream[2] = {nullptr, nullptr};
+    int kernel_streams = 1;                    // 1: every pass on one stream; 2 .. 4: consecutive passes take the streams in turn
+    hipStream_t kstream[4] = {nullptr, nullptr, nullptr, nullptr};
     int flip = 0;
+    int streams_used = 1;                      // how many streams the last submit took its turn over
     bool used_two_streams = false;
     std::vector<Slot> slots;
     std::deque<uint32_t> in_flight;            // slot numbers, oldest first
@@ -75,7 +76,7 @@ static void free_slot(Slot& s, const uint64_t* keep) {
 extern "C" void havac_pipe_destroy(havac_pipe* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    for (int k = 0; k < 2; k++) if (p->kstream[k]) (void)hipStreamSynchronize(p->kstream[k]);
+    for (int k = 0; k < 4; k++) if (p->kstream[k]) (void)hipStreamSynchronize(p->kstream[k]);
     for (Slot& s : p->slots) {
         free_slot(s, nullptr);
         if (s.gathered) (void)hipEventDestroy(s.gathered);
@@ -83,19 +84,23 @@ extern "C" void havac_pipe_destroy(havac_pipe* p) {
         if (s.g1) (void)hipEventDestroy(s.g1);
     }
     if (p->inputs) (void)hipEventDestroy(p->inputs);
-    for (int k = 0; k < 2; k++) if (p->kstream[k]) (void)hipStreamDestroy(p->kstream[k]);
+    for (int k = 0; k < 4; k++) if (p->kstream[k]) (void)hipStreamDestroy(p->kstream[k]);
     delete p;
 }
 
 extern "C" int havac_pipe_create(uint32_t depth, uint64_t hit_capacity, int kernel_streams, havac_pipe** out) {
-    if (!out || depth == 0 || depth > 8 || kernel_streams == 0 || kernel_streams > 2) return HAVAC_E_ARGUMENT;
+    if (!out || depth == 0 || depth > 8 || kernel_streams == 0 || kernel_streams > 4) return HAVAC_E_ARGUMENT;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return HAVAC_E_NO_DEVICE;
     havac_pipe* p = new (std::nothrow) havac_pipe;
     if (!p) return HAVAC_E_NOMEM;
     p->depth = depth; p->hit_capacity = hit_capacity;
-    p->kernel_streams = kernel_streams < 0 ? (depth > 1 ? 2 : 1) : (depth > 1 ? kernel_streams : 1);
+    // (-1, the library's rule: two.  Three or four are for experiments: with three, 64 rows x 100 Mbp gained 10 % per step on three
+    // boxes (44.8 -> 49.5 TCUPS), 32 rows gained 11 % on one box and LOST 14 % on two, taller passes moved by -9 ... +2 %
+    // (profiles/r05t_step_probe_*): how the command processor interleaves three queues of eight short launches each is not
+    // something a rule can be built on; two streams have measured the same on every box of rounds 4 and 5.)
+    p->kernel_streams = kernel_streams < 0 ? std::min<int>(2, (int)depth) : std::min<int>(kernel_streams, (int)depth);
     auto body = [&]() -> int {
         PIPE_HIP(p, hipGetDevice(&p->device));
         int least = 0, greatest = 0;
@@ -104,8 +109,7 @@ extern "C" int havac_pipe_create(uint32_t depth, uint64_t hit_capacity, int kern
         // records -- is one stream's business, consecutive passes alternate, so a kernel starts while its predecessor drains (the
         // last, half-empty round of a launch's tiles and the ~16 us between two dependent launches are filled by its neighbour's
         // first workgroups: C2 1.878 -> 1.78 ms per step, less than one kernel takes alone) and runs beside its predecessor's ordering
-        PIPE_HIP(p, hipStreamCreateWithPriority(&p->kstream[0], hipStreamNonBlocking, greatest));
-        if (p->kernel_streams == 2) PIPE_HIP(p, hipStreamCreateWithPriority(&p->kstream[1], hipStreamNonBlocking, greatest));
+        for (int k = 0; k < p->kernel_streams; k++) PIPE_HIP(p, hipStreamCreateWithPriority(&p->kstream[k], hipStreamNonBlocking, greatest));
         (void)least;
         PIPE_HIP(p, hipEventCreateWithFlags(&p->inputs, hipEventDisableTiming));
         p->slots.resize(depth);
@@ -128,6 +132,7 @@ extern "C" const char* havac_pipe_last_error(havac_pipe* p) { return p ? p->err.
 extern "C" uint32_t havac_pipe_depth(havac_pipe* p) { return p ? p->depth : 0; }
 extern "C" uint32_t havac_pipe_in_flight(havac_pipe* p) { return p ? (uint32_t)p->in_flight.size() : 0; }
 extern "C" int havac_pipe_used_two_streams(havac_pipe* p) { return p && p->used_two_streams ? 1 : 0; }
+extern "C" int havac_pipe_streams_used(havac_pipe* p) { return p ? p->streams_used : 0; }
 
 extern "C" havac_ssv_ctx* havac_pipe_context(havac_pipe* p, int which) {
     if (!p || p->released) return nullptr;
@@ -153,8 +158,10 @@ extern "C" int havac_pipe_submit(havac_pipe* p, const uint8_t* d_sequence, uint6
     Slot& s = p->slots[p->next];
     hipStream_t stream = p->kstream[0];
     if (p->kstream[1]) {
+        const int n = p->kernel_streams;
         p->used_two_streams = true;
-        p->flip ^= 1;
+        p->streams_used = n;
+        p->flip = (p->flip + 1) % n;
         stream = p->kstream[p->flip];
     }
     s.stream = stream;
@@ -309,7 +316,7 @@ extern "C" int havac_pipe_release(havac_pipe* p) {
     if (!p) return HAVAC_E_ARGUMENT;
     if (!p->in_flight.empty()) { p->err = "passes are in flight: collect them first"; return HAVAC_E_LOGIC; }
     PIPE_HIP(p, hipSetDevice(p->device));
-    for (int k = 0; k < 2; k++) if (p->kstream[k]) PIPE_HIP(p, hipStreamSynchronize(p->kstream[k]));
+    for (int k = 0; k < 4; k++) if (p->kstream[k]) PIPE_HIP(p, hipStreamSynchronize(p->kstream[k]));
     for (Slot& s : p->slots) {
         harvest(p, s);
         free_slot(s, p->last_records);

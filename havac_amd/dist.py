@@ -316,8 +316,8 @@ class ShardedSsv:
         for SsvContext.set_tuning / set_split_tuning / set_kernel_variant (experiments)"""
         from . import _lib
         from .ssv import SsvContext
-        if kernel_streams not in (None, 1, 2):
-            raise ValueError("kernel_streams: None (the library's rule), 1 or 2")
+        if kernel_streams not in (None, 1, 2, 3, 4):
+            raise ValueError("kernel_streams: None (the library's rule) or 1 .. 4")
         self._L = _lib.load()
         self.device = device
         self.depth = max(1, depth)
@@ -367,6 +367,11 @@ class ShardedSsv:
     @property
     def used_two_streams(self) -> bool:
         return bool(self._L.havac_pipe_used_two_streams(self._h))
+
+    @property
+    def streams_used(self) -> int:
+        """how many streams the last submit took its turn over (1: every pass on one stream)"""
+        return int(self._L.havac_pipe_streams_used(self._h))
 
     def set_sequence_window(self, first_column: int = 0, ncolumns: int = 0):
         """the d_seq handed to submit() holds columns [first_column, first_column + ncolumns) of the database only

@@ -413,8 +413,9 @@ const char *havac_ssv_ctx_last_error(havac_ssv_ctx *ctx);
  * keeps up to `depth` passes in flight on the device that is current when it is created, each in a slot of its own -- a context
  * and a hit buffer of hit_capacity records -- and each, from its first kernel to the ordering of its records, on ONE of two
  * high-priority streams that consecutive passes alternate between (kernel_streams: -1 = that; 1 = every pass on the same stream;
- * 2): while the host waits for pass k and its records are ordered and gathered, the kernel of pass k + 1 runs -- and has started
- * while kernel k was draining.  depth 1 is the reference's behaviour.
+ * 2 .. 4 = that many streams taken in turn, three and four for experiments): while the host waits for pass k and its records are
+ * ordered and gathered, the kernel of pass k + 1 runs -- and has started while kernel k was draining.  depth 1 is the reference's
+ * behaviour.
  *
  *   havac_pipe_submit   enqueues one whole pass (as havac_ssv_enqueue; all pointers are DEVICE pointers the caller keeps alive)
  *                       behind what `caller_stream` holds now (the inputs' producer; HAVAC_NO_STREAM: nothing to wait for);
@@ -452,6 +453,7 @@ int havac_pipe_wait_inputs(havac_pipe *pipe, int sequence_too);
 uint32_t havac_pipe_depth(havac_pipe *pipe);
 uint32_t havac_pipe_in_flight(havac_pipe *pipe);
 int havac_pipe_used_two_streams(havac_pipe *pipe);
+int havac_pipe_streams_used(havac_pipe *pipe);      /* how many streams the last submit took its turn over */
 havac_ssv_ctx *havac_pipe_context(havac_pipe *pipe, int which);
 int havac_pipe_set_gather(havac_pipe *pipe, havac_gather *gather);
 int havac_pipe_wait_gathers(havac_pipe *pipe);

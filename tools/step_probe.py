@@ -37,11 +37,11 @@ def main():
             print(f"rows {rows} bare context on {name}: found {found} step {step:.4f} ms = {ncols * rows / step / 1e9:.2f} TCUPS", flush=True)
         ctx.close()
         del hits
-        for depth, streams in ((1, None), (2, 1), (2, 2), (3, 1), (3, 2)):
+        for depth, streams in ((1, None), (2, 2), (3, None), (3, 2), (3, 3)):
             eng = ShardedSsv(cap, dev, depth=depth, kernel_streams=streams)
             eng.run_many(20, d_seq, ncols, d_phmm, rows)
             torch.cuda.synchronize(dev)
-            n = 60
+            n = 120
             t0 = time.perf_counter()
             (recs, found), ms = eng.run_many(n, d_seq, ncols, d_phmm, rows, inputs_ready=True)
             torch.cuda.synchronize(dev)
