@@ -37,8 +37,15 @@ def main():
             print(f"rows {rows} bare context on {name}: found {found} step {step:.4f} ms = {ncols * rows / step / 1e9:.2f} TCUPS", flush=True)
         ctx.close()
         del hits
-        for depth, streams in ((1, None), (2, 2), (3, None), (3, 2), (3, 3)):
+        for depth, streams, order_streams in ((1, None, 0), (2, 2, 0), (3, 2, 0), (3, 3, 0), (2, 1, 1), (3, 1, 1), (2, 2, 1), (3, 2, 1)):
             eng = ShardedSsv(cap, dev, depth=depth, kernel_streams=streams)
+            keep = []
+            if order_streams:      # every slot orders on a HIGH-priority stream of its own (round 4 had them at low priority)
+                import ctypes as C
+                for i in range(depth):
+                    st = torch.cuda.Stream(dev, priority=-1)
+                    keep.append(st)
+                    eng._L.havac_ssv_set_order_stream(C.c_void_p(eng._L.havac_pipe_context(eng._h, i)), C.c_void_p(st.cuda_stream))
             eng.run_many(20, d_seq, ncols, d_phmm, rows)
             torch.cuda.synchronize(dev)
             n = 120
@@ -48,7 +55,7 @@ def main():
             step = (time.perf_counter() - t0) / n * 1e3
             k = sum(m[0] for m in ms) / len(ms)
             tot = sum(m[1] for m in ms) / len(ms)
-            print(f"rows {rows} depth {depth} kernel streams {streams}: found {found} step {step:.4f} ms = {ncols * rows / step / 1e9:.2f} TCUPS; kernel {k:.4f} ms, enqueue-to-ordered {tot:.4f} ms", flush=True)
+            print(f"rows {rows} depth {depth} kernel streams {streams}{' + an ordering stream per slot' if order_streams else ''}: found {found} step {step:.4f} ms = {ncols * rows / step / 1e9:.2f} TCUPS; kernel {k:.4f} ms, enqueue-to-ordered {tot:.4f} ms", flush=True)
             eng.release()
 
 
