@@ -350,6 +350,46 @@ def test_havac_benchmark_repeats_with_runs_in_flight(tmp_path):
         assert "the same list every run: yes" in out.stdout and f"30 runs, {depth} in flight" in out.stdout and "GCUPS" in out.stdout
 
 
+def test_the_cxx_drop_in_reaches_the_engines_rate_on_c2(tmp_path):
+    """"a C++ test (havac_benchmark --repeat 50) reaching within 1 % of bench.py's value on C2 with no
+    Python in the process".  bench.py's C2 workload as files, `havac_benchmark --raw --repeat 100 --depth 3 --no-readback` (the
+    handle API: havac_dev_run_async / _wait / _num_hits64 / _retire), and the same passes through bench.py's own engine
+    (ShardedSsv = havac_pipe_run) in this process, on the same GPU one after the other.  Asserted at 3 % -- the two are measured
+    seconds apart, and boxes wander by a per cent; the profiles (r05j_*) have them within 0.3 %."""
+    import os
+    import re
+    import subprocess
+    import sys
+    import time
+    import torch
+    from conftest import ROOT
+    from havac_amd import havac
+    from havac_amd.dist import ShardedSsv
+    sys.path.insert(0, ROOT)
+    import bench
+    prefix = str(tmp_path / "c2")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dump_workload.py"), "--workload", "c2", prefix], check=True, capture_output=True, timeout=300)
+    exe = os.path.join(os.path.dirname(havac.HOST_LIB_PATH), "havac_benchmark")
+    out = subprocess.run([exe, "--raw", prefix + ".seq", prefix + ".model", "--repeat", "100", "--depth", "3", "--no-readback"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "the same list every run: yes" in out.stdout and "1012547 hits per run" in out.stdout, out.stdout
+    cxx = float(re.search(r"= ([0-9.]+) GCUPS", out.stdout).group(1))
+    model, packed, ncols, _, _ = bench.make_inputs("c2", 1, 0, 0)
+    dev = torch.device("cuda", 0)
+    d_seq, d_phmm = torch.from_numpy(packed).to(dev), torch.from_numpy(model.reshape(-1)).to(dev)
+    eng = ShardedSsv(1 << 22, dev, depth=3)
+    eng.run_many(20, d_seq, ncols, d_phmm, model.shape[0])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    (_, found), _ = eng.run_many(100, d_seq, ncols, d_phmm, model.shape[0], inputs_ready=True)
+    torch.cuda.synchronize(dev)
+    engine = ncols * model.shape[0] / ((time.perf_counter() - t0) / 100) / 1e9
+    eng.release()
+    assert found == 1012547
+    assert cxx > 50000 and cxx >= 0.97 * engine, (cxx, engine)
+
+
 def test_havac_benchmark_binary(tmp_path):
     """The counterpart of benchmark/benchmark.cpp runs and prints the reference's timing lines."""
     import os
