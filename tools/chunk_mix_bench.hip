@@ -50,6 +50,42 @@ __device__ __forceinline__ void chunk(uint32_t (&a)[16], uint32_t (&b)[16], cons
     }
 }
 
+// the same bytes from LDS in HALF as many instructions: a window's four match words of a register in one ds_read_b128 (a
+// table such reads could index does not fit LDS -- 4 KB per window and wave; this only asks whether a read's cost to the
+// vector issue goes by the instruction or by the byte)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u32x4* lds_quad_t;
+template <int ORS>
+__device__ __forceinline__ void chunk_b128(uint32_t (&a)[16], uint32_t (&b)[16], const uint32_t (&C)[32], uint32_t mask, uint32_t& hits) {
+#pragma unroll
+    for (int Q = 0; Q < 8; Q++) {
+        uint32_t (&cur)[16] = (Q & 1) ? b : a;
+        uint32_t (&nxt)[16] = (Q & 1) ? a : b;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {               // four registers at a time: 4 reads of 16 B, 16 adds
+            u32x4 m[4];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) m[i] = *(lds_quad_t)(uintptr_t)(((C[2 * Q + g * 4 + i] + (2 * Q) * kPairStride) & ~15u));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) asm volatile("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(nxt[g * 4 + i]) : "v"(cur[g * 4 + i]), "v"(m[i].x));
+#pragma unroll
+            for (int i = 0; i < 4; i++) asm volatile("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[g * 4 + i]) : "v"(m[i].y));
+#pragma unroll
+            for (int i = 0; i < 4; i++) asm volatile("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[g * 4 + i]) : "v"(m[i].z));
+#pragma unroll
+            for (int i = 0; i < 4; i++) asm volatile("v_pk_add_i16 %0, %0, %1 clamp" : "+v"(nxt[g * 4 + i]) : "v"(m[i].w));
+        }
+        if constexpr (ORS) {
+            uint32_t any = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) any |= nxt[i];
+            if (__builtin_expect(__ballot((any & mask) != 0) != 0, 0)) { hits++; nxt[0] = 0x80008000u; }
+        }
+    }
+}
+
 template <int W, int READS, int ORS>
 __global__ __launch_bounds__(256, W) void k(uint32_t* out, const uint32_t* codes, uint32_t mask, uint32_t filler, uint64_t* clocks) {
     __shared__ __attribute__((aligned(128))) uint8_t tables[4][kTableBytes + 1024];
@@ -65,7 +101,10 @@ __global__ __launch_bounds__(256, W) void k(uint32_t* out, const uint32_t* codes
     for (int i = 0; i < 16; i++) a[i] = b[i] = 0x80008000u;
     const uint64_t c0 = __builtin_readcyclecounter(), w0 = wall_clock64();      // shader-clock cycles (s_memtime) and the 100 MHz clock
 #pragma unroll 1
-    for (int c = 0; c < kChunks; c++) chunk<READS, ORS>(a, b, C, mask, hits, filler);
+    for (int c = 0; c < kChunks; c++) {
+        if constexpr (READS == 2) chunk_b128<ORS>(a, b, C, mask, hits);
+        else chunk<READS, ORS>(a, b, C, mask, hits, filler);
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = __builtin_readcyclecounter() - c0; clocks[1] = wall_clock64() - w0; }
     uint32_t r = hits;
 #pragma unroll
@@ -114,6 +153,8 @@ int main() {
     run<6, 0, 1>("adds + OR tree + test", out, codes, cus, ghz);
     run<6, 1, 0>("adds + 256 ds_read_b64", out, codes, cus, ghz);
     run<6, 1, 1>("adds + reads + OR tree + test (the chunk's mix)", out, codes, cus, ghz);
+    run<6, 2, 0>("adds + 128 ds_read_b128 (the same bytes, half the reads)", out, codes, cus, ghz);
+    run<6, 2, 1>("adds + 128 ds_read_b128 + OR tree + test", out, codes, cus, ghz);
     run<4, 1, 1>("adds + reads + OR tree + test", out, codes, cus, ghz);
     run<5, 1, 1>("adds + reads + OR tree + test", out, codes, cus, ghz);
     std::free(h);
