@@ -1,0 +1,42 @@
+"""How long a wave is away in the slow path (experiments: a build with -DHAVAC_SLOW_CLOCKS as tools/_bin/ab/libS.so -- s_memtime at
+the slow path's entry and exit, summed per launch).   python3 tools/slow_path_clocks.py [rows ...]"""
+import ctypes as C
+import os
+import shutil
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+lib_path = os.path.join(ROOT, "havac_amd", "libhavac_dev.so")
+kept = lib_path + ".kept"
+shutil.copyfile(lib_path, kept)
+shutil.copyfile(os.path.join(ROOT, "tools", "_bin", "ab", "libS.so"), lib_path)
+try:
+    import torch
+    from havac_amd import synth
+    from havac_amd.dist import ShardedSsv
+    L = C.CDLL(lib_path)
+    dev = torch.device("cuda", 0)
+    ncols = 100_012_032
+    d_seq = torch.from_numpy(synth.random_packed(ncols, synth.SEED_SEQUENCE)).to(dev)
+    eng = ShardedSsv(1 << 23, dev)
+    for nrows in [int(a) for a in sys.argv[1:]] or [1024, 64]:
+        model = synth.dfam_like_model(nrows, synth.SEED_MODEL)[0]
+        d_phmm = torch.from_numpy(model.reshape(-1)).to(dev)
+        for _ in range(3):
+            eng.run(d_seq, ncols, d_phmm, nrows)
+        buf = (C.c_uint64 * 2)()
+        assert L.havac_debug_slow_clocks(buf, 1) == 0
+        _, found = eng.run(d_seq, ncols, d_phmm, nrows)
+        ms = eng.ctx.last_ms()[0]
+        assert L.havac_debug_slow_clocks(buf, 1) == 0
+        cycles, entries = int(buf[0]), int(buf[1])
+        chunks = ncols * nrows / (2048 * 32)
+        print(f"rows {nrows}: kernel {ms:.4f} ms (this build: two atomics per entry), {found} hits, {entries} slow-path entries, "
+              f"{cycles / max(entries, 1):.0f} shader cycles per entry; a wave's chunk takes {ms * 1e-3 * 2.4e9 * 1024 * 6 / chunks:.0f} cycles of its life "
+              f"(six waves per SIMD) -> an entry = {cycles / max(entries, 1) / (ms * 1e-3 * 2.4e9 * 1024 * 6 / chunks) * 8:.2f} windows of it", flush=True)
+finally:
+    shutil.copyfile(kept, lib_path)
+    os.remove(kept)
