@@ -194,6 +194,39 @@ def test_runs_in_flight_behind_the_handle(oracle):
     c.close()
 
 
+def test_an_overflowing_run_between_two_good_ones(oracle):
+    """Three runs, two open at once; the middle one finds more records than the hit buffer holds: it alone ends in ERROR (5) with
+    HitOverflowError on its list, the runs before and after it are unaffected (every run has its own slot: context, hit buffer,
+    report) -- the reference's client has one buffer and one run, host/HavacHwClient.cpp:141-202."""
+    from havac_amd.hw_client import HavacHwClient, HitOverflowError
+    sym, model_a = small_inputs(nrows=300, nseg=12, seed=5)
+    dense = np.full((40, 4), 127, np.int8)                         # a hit on every third row of every diagonal: far more than the buffer
+    model_c, _ = synth.dfam_like_model(500, 17)
+    want_a, want_c = oracle.ssv_fast(sym, model_a), oracle.ssv_fast(sym, model_c)
+    capacity = max(want_a.size, want_c.size) + 64
+    assert oracle.ssv_fast(sym, dense).size > 4 * capacity
+    c = HavacHwClient()
+    c.setHitCapacity(capacity)
+    c.setPipelineDepth(2)
+    c.writeSequence(synth.pack_2bit(sym))
+    c.writePhmm(model_a)
+    c.invokeHavacSsvAsync()
+    c.writePhmm(dense)
+    c.invokeHavacSsvAsync()
+    assert c.waitForHavacSsvAsync() == 4 and np.array_equal(c.getHitList(), want_a)
+    c.retire()
+    c.writePhmm(model_c)
+    c.invokeHavacSsvAsync()                                         # beside the overflowing run
+    assert c.waitForHavacSsvAsync() == 5                            # the oldest open run: the dense one -- ERROR
+    with pytest.raises(HitOverflowError):
+        c.getHitList()
+    c.retire()
+    assert c.waitForHavacSsvAsync() == 4 and np.array_equal(c.getHitList(), want_c)
+    c.retire()
+    assert c.openRuns() == 0
+    c.close()
+
+
 def test_runs_in_flight_over_several_gpus(oracle):
     """the same with four device parts behind the handle (one GPU named four times): every part keeps two passes in flight"""
     from havac_amd.hw_client import HavacHwClient
