@@ -21,14 +21,14 @@ try:
     dev = torch.device("cuda", 0)
     ncols = 100_012_032
     d_seq = torch.from_numpy(synth.random_packed(ncols, synth.SEED_SEQUENCE)).to(dev)
-    eng = ShardedSsv(1 << 23, dev, tuning=[-1, -1, -1, -1, -1, -1, -1, -1, 1])
+    eng = ShardedSsv(1 << 23, dev)
     for nrows in [int(a) for a in sys.argv[1:]] or [32, 256]:
         model = np.full((nrows, 4), -3, np.int8)
         d_phmm = torch.from_numpy(model.reshape(-1)).to(dev)
         for _ in range(4):
             eng.run(d_seq, ncols, d_phmm, nrows)
         ms = eng.ctx.last_ms()[0]
-        n = 6144
+        n = 16384
         buf = np.zeros(n * 4, np.uint64)
         assert L.havac_debug_wave_clocks(buf.ctypes.data_as(C.c_void_p), n) == 0
         d = buf.reshape(n, 4)
