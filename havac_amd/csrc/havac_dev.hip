@@ -373,8 +373,8 @@ extern "C" int havac_debug_wave_clocks(uint64_t* out, uint32_t nwaves) {      //
 #endif
 #ifdef HAVAC_SLOW_CLOCKS
 extern "C" int havac_debug_slow_clocks(uint64_t* out, int reset) {      // experiments only: see g_slow_clocks
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slow_clocks), 2 * sizeof(uint64_t)) != hipSuccess) return 1;
-    const uint64_t zero[2] = {0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slow_clocks), 4 * sizeof(uint64_t)) != hipSuccess) return 1;
+    const uint64_t zero[4] = {0, 0, 0, 0};
     return reset && hipMemcpyToSymbol(HIP_SYMBOL(g_slow_clocks), zero, sizeof zero) != hipSuccess ? 1 : 0;
 }
 #endif

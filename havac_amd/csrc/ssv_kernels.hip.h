@@ -713,8 +713,8 @@ __device__ __forceinline__ void find_marked(uint32_t l, const uint32_t (&cur)[kR
 #ifdef HAVAC_SLOW_CLOCKS
 // experiments only (tools/slow_path_clocks.py): shader-clock cycles (s_memtime) the waves spent inside the slow path, and its entries;
 // summed per workgroup in LDS (one atomic pair per entry on one global word would be the slowest thing in the kernel), per launch here
-__device__ unsigned long long g_slow_clocks[2];
-__shared__ unsigned long long s_slow_clocks[2];
+__device__ unsigned long long g_slow_clocks[4];      // [2], [3]: s_memtime and s_memrealtime (100 MHz) over the workgroups' lives, summed: the shader clock the launch really saw
+__shared__ unsigned long long s_slow_clocks[4];      // [2], [3] here: the two clocks at the workgroup's start
 #endif
 // `marked` (per lane) = OR of the score registers after NSTEPS (2 or 4) steps of window Q.  For every lane and register
 // that shows a mark: take the register's NSTEPS steps again on the scalar unit from `cur` (the scores the window started
@@ -726,7 +726,7 @@ template <bool Resident, int Q, int NSTEPS, int... I>
 __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
                                             unsigned long long lanes, int report_from, const HitSink& sink, uint32_t& staged,
                                             uint32_t step0, int64_t wave_diag0, std::integer_sequence<int, I...>) {
-#ifdef HAVAC_SLOW_CLOCKS
+#if defined(HAVAC_SLOW_CLOCKS) && HAVAC_SLOW_CLOCKS > 1      // (-DHAVAC_SLOW_CLOCKS=1: only the launch's shader clock, the kernel runs at its usual speed)
     const uint64_t slow_t0 = __builtin_readcyclecounter();
 #endif
     // the shard's columns, from the kernarg segment: the loads are issued here and are back long before a cell is reported
@@ -799,7 +799,7 @@ __device__ __forceinline__ void window_slow(const uint32_t (&cur)[kRegs], uint32
         for (int i = 0; i < kRegs; i++) marked |= nxt[i];
         lanes = __ballot((marked & kCrossedBits) != 0);
     } while (lanes);
-#ifdef HAVAC_SLOW_CLOCKS
+#if defined(HAVAC_SLOW_CLOCKS) && HAVAC_SLOW_CLOCKS > 1      // (-DHAVAC_SLOW_CLOCKS=1: only the launch's shader clock, the kernel runs at its usual speed)
     if (fresh_lane() == 0) { atomicAdd(&s_slow_clocks[0], (unsigned long long)(__builtin_readcyclecounter() - slow_t0)); atomicAdd(&s_slow_clocks[1], 1ull); }
 #endif
 }
@@ -936,7 +936,11 @@ __device__ __forceinline__ void step_windows(uint32_t (&a)[kRegs], uint32_t (&b)
 __device__ __forceinline__ void leave_block(const uint64_t* const stage, const uint32_t staged, const uint32_t wave) {
 #ifdef HAVAC_SLOW_CLOCKS
     __syncthreads();
-    if (threadIdx.x == 0 && s_slow_clocks[1]) { atomicAdd(&g_slow_clocks[0], s_slow_clocks[0]); atomicAdd(&g_slow_clocks[1], s_slow_clocks[1]); }
+    if (threadIdx.x == 0) {
+        if (s_slow_clocks[1]) { atomicAdd(&g_slow_clocks[0], s_slow_clocks[0]); atomicAdd(&g_slow_clocks[1], s_slow_clocks[1]); }
+        atomicAdd(&g_slow_clocks[2], (unsigned long long)__builtin_readcyclecounter() - s_slow_clocks[2]);
+        atomicAdd(&g_slow_clocks[3], (unsigned long long)wall_clock64() - s_slow_clocks[3]);
+    }
 #endif
     // What is still staged when the block ends.  A returning atomic on the one counter word is the obvious way out, and
     // for short models the wrong one: the word sustains ~90 returning atomics per microsecond chip-wide, a launch of
@@ -1004,7 +1008,7 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
                                               const uint32_t nrows_padded) {
     __shared__ WaveLds wave_lds[kWavesPerBlock];
 #ifdef HAVAC_SLOW_CLOCKS
-    if (threadIdx.x == 0) s_slow_clocks[0] = s_slow_clocks[1] = 0;
+    if (threadIdx.x == 0) { s_slow_clocks[0] = s_slow_clocks[1] = 0; s_slow_clocks[2] = __builtin_readcyclecounter(); s_slow_clocks[3] = wall_clock64(); }
     __syncthreads();
 #endif
 
@@ -1336,7 +1340,7 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
                                                   const uint32_t nrows_padded) {
     __shared__ ResidentLds lds;
 #ifdef HAVAC_SLOW_CLOCKS
-    if (threadIdx.x == 0) s_slow_clocks[0] = s_slow_clocks[1] = 0;
+    if (threadIdx.x == 0) { s_slow_clocks[0] = s_slow_clocks[1] = 0; s_slow_clocks[2] = __builtin_readcyclecounter(); s_slow_clocks[3] = wall_clock64(); }
 #endif
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const HitSink sink{lds.stage[wave]};
