@@ -227,8 +227,13 @@ extern "C" int havac_gather_create(uint32_t rank, uint32_t world, const uint8_t 
         GATHER_HIP(g, hipGetDevice(&g->device));
         int least = 0, greatest = 0;
         GATHER_HIP(g, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        // low priority: the gather of pass k runs beside the SSV kernel of pass k + 1 and must not take its compute units
-        GATHER_HIP(g, hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, least));
+        // HIGH priority, as the pipe's kernel streams (round 5; rounds 3-4: low, "the gather must not take the next kernel's compute
+        // units").  The gather of pass k runs beside the SSV kernels of passes k + 1 and k + 2, which always have workgroups waiting
+        // for a wave slot: a low-priority launch beside them waits 30 - 330 us on average for its first slot (measured with this
+        // round's ordering kernels), and here the HOST waits for the count exchange -- eight ranks' worth of
+        // such delays, the slowest one counts -- before it can submit the pass after next.  What the collective's few workgroups
+        // take from an SSV kernel for the 0.2 ms of an 8 MB transfer is below a per cent; a pipeline that runs dry is not.
+        GATHER_HIP(g, hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, greatest));
         GATHER_HIP(g, hipEventCreateWithFlags(&g->before, hipEventDisableTiming));
         GATHER_HIP(g, hipEventCreateWithFlags(&g->after, hipEventDisableTiming));
         GATHER_HIP(g, hipMalloc(&g->d_counts, ((size_t)world + 1) * sizeof(int64_t)));
