@@ -353,9 +353,10 @@ class ShardedSsv:
             if g is not None:
                 self._c_route = True
                 self._check(self._L.havac_pipe_set_gather(self._h, g._h))
-            elif self.depth > 1:      # the torch route: the gather of a slot runs on a low-priority stream of its own
-                low, _high = torch.cuda.Stream.priority_range()
-                self._py_streams = [torch.cuda.Stream(device, priority=low) for _ in range(self.depth)]
+            elif self.depth > 1:      # the torch route: the gather of a slot runs on a stream of its own, at the kernel streams'
+                #                       priority (the host waits for its count exchange: havac_gather.hip says why it is not low)
+                _low, high = torch.cuda.Stream.priority_range()
+                self._py_streams = [torch.cuda.Stream(device, priority=high) for _ in range(self.depth)]
         self.gather_ms = []               # device time of each gather on this rank (filled by gather_times())
         self._timed = []
 
