@@ -718,9 +718,10 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     HIP_TRY(c->err, hipEventRecord(c->ev[0], stream));
     // one launch: the padded copy of the model, the chunk flags, and everything the pass's kernels count in, cleared -- the hit
     // counter, the tickets, the tails' sums, the ordering's barrier words, the hand-off counts of cut tiles.  (Separator pairs
-    // score -128 twice in a row whatever the model says: with a mask there are no flags, every chunk tests every two steps.)
+    // score -128 twice in a row whatever the model says: with a mask the kernel takes a chunk's flag only where no separator and no
+    // edge of the matrix lies in the wave's window, see ssv_diag_body.)
     {
-        const uint32_t nflagwords = c->pair_mask ? 0u : flag_words;
+        const uint32_t nflagwords = flag_words;
         const uint32_t threads = std::max(std::max(model_words, nflagwords * 32u), kControlWords);
         hipLaunchKernelGGL(ssv_prepare_model, dim3((threads + 255) / 256), dim3(256), 0, stream, d_phmm, nrows, c->rows8, model_words,
                            t.nrows_padded, c->chunk_flags, nflagwords, c->d_count, c->control, kControlWords, c->block_flags, (uint32_t)handoff_words);
@@ -735,7 +736,9 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         R.tails = use_tails ? c->tails : nullptr; R.tail_counts = use_tails ? c->tail_counts : nullptr;
         R.cells = c->trace_cells; R.cell_row0 = c->trace_row0; R.cell_col0 = (int64_t)c->trace_col0;
         R.cell_rows = c->trace_rows; R.cell_cols = c->trace_cols;
-        const uint32_t* const safe_chunks = c->pair_mask ? (const uint32_t*)nullptr : (const uint32_t*)c->chunk_flags;
+        // (round 5: the chunk flags are handed over with a separator mask too -- a chunk then tests every two steps only where a
+        // separator, or the matrix's edge, really lies in the wave's window; the kernel sees the mask in SsvRare::pair_mask)
+        const uint32_t* const safe_chunks = (const uint32_t*)c->chunk_flags;
         c->last_resident_kernel = resident_kernel;
         if (c->trace_cells)       // debugging: the same kernel body with the per-cell trace compiled in
             hipLaunchKernelGGL(ssv_diag_kernel_traced, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,

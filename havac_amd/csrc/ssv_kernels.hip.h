@@ -361,7 +361,7 @@ struct SsvRare {
     int64_t col_begin;             // only hits in columns [col_begin, col_begin + col_span) are reported (the shard's own columns)
     uint64_t col_span;
     const uint32_t* abort_flag;    // optional device word: non-zero = stop
-    const uint16_t* pair_mask;     // separator bitmap (boundary mode); the kernel is given safe_chunks == nullptr exactly when it is set
+    const uint16_t* pair_mask;     // separator bitmap (boundary mode), or null
     uint32_t* tickets;             // the ticket counter of row-split launches
     uint32_t* block_flags;         // per CUT tile of this launch (see handoff slots, "items"): row blocks finished
     uint32_t* block_state;         // per cut tile: 8 x 64 words = the 2048 scores (a byte each) handed from one row block to the next
@@ -1013,9 +1013,9 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
 #endif
 
     const uint32_t lane = threadIdx.x & 63;
-    // a separator mask is in use exactly when there are no chunk flags; as a 32-bit SGPR flag tested afresh (fresh_uniform), not a
-    // lane mask that is copied through -- and once spilled from -- a VGPR
-    const uint32_t has_mask = opaque_uniform(safe_chunks == nullptr ? 1u : 0u);
+    // is a separator mask in use?  As a 32-bit SGPR flag tested afresh (fresh_uniform), not a lane mask that is copied through -- and
+    // once spilled from -- a VGPR
+    const uint32_t has_mask = opaque_uniform(rare_args()->pair_mask != nullptr ? 1u : 0u);
     // readfirstlane: everything derived from the tile index is wave-uniform (SALU branches, scalar address math)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds* const lds = &wave_lds[wave];
@@ -1181,6 +1181,7 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         LazySymbols z;
         LaneWords mine = read_lane_words(lane_words_address);
         fetch_symbols(p_begin, z, mine.lane8);
+        uint32_t lower_special = z.special & kFlagSpecial;                 // (wave-uniform; see the chunk loop)
         if (__builtin_amdgcn_readfirstlane(abort_now)) return false;       // (a scalar branch: every lane read the same word)
         expand_all(C, z, std::make_integer_sequence<int, 16>{});       // -> C[16..32): the first chunk's lower half after the slide
         ModelRows next_rows = fetch_rows(p_begin, mine);
@@ -1196,14 +1197,17 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         // cost 2 % (an LDS-DMA instruction costs the wave more issue time than the wait it saves).  DESIGN.md section 7b.
 
         bool go_on = true;                 // wave-uniform
-        // one bit per chunk: may the chunk look for hits every four steps only (ssv_prepare_model)?  never with separators.
-        // The word of the current 1024 rows and, loaded a whole block ahead, the next one: the test never waits for memory
-        uint32_t safe_now = safe_chunks ? safe_chunks[p_begin >> 10] : 0u;
-        uint32_t safe_next = safe_chunks ? safe_chunks[(p_begin >> 10) + 1] : 0u;
+        // one bit per chunk: may the chunk look for hits every four steps only (ssv_prepare_model)?
+        // The word of the current 1024 rows and, loaded a whole block ahead, the next one: the test never waits for memory.
+        // With a separator mask (round 5; before: never) a chunk may, too, unless a separator pair or the matrix's edge lies in the wave's
+        // window of 64 symbols: the "outside" entry then scores -128, two of them take a crossed cell's mark away inside a window.
+        // `lower_special`: the flag of the symbols that have slid into the window's lower half (z.special holds the upper half's).
+        uint32_t safe_now = safe_chunks[p_begin >> 10];
+        uint32_t safe_next = safe_chunks[(p_begin >> 10) + 1];
         for (uint32_t p0 = p_begin; p0 < p_end; p0 += kChunkRows) {
             if ((p0 & 1023) == 0 && p0 != p_begin) {
                 safe_now = safe_next;
-                safe_next = safe_chunks ? safe_chunks[(p0 >> 10) + 1] : 0u;
+                safe_next = safe_chunks[(p0 >> 10) + 1];
             }
             // abort: a device word, read past the caches every 2048 rows inside an item (and between items, below)
             if (((p0 & 2047) == 0) && p0 != p_begin) {
@@ -1214,7 +1218,13 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             // slide the window by 32 symbols
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-            z.special = opaque_uniform(((safe_now >> ((p0 >> 5) & 31u)) & 1u) | (z.special & kFlagSpecial));     // + kFlagSafe for this chunk
+            {
+                const uint32_t upper_special = z.special & kFlagSpecial;
+                uint32_t safe_bit = (safe_now >> ((p0 >> 5) & 31u)) & 1u;
+                if (fresh_uniform(has_mask) && (lower_special | upper_special)) safe_bit = 0;
+                lower_special = upper_special;                    // (what it is once this chunk's symbols have slid down)
+                z.special = opaque_uniform(safe_bit | upper_special);     // + kFlagSafe for this chunk
+            }
             step_windows<Trace, false>(x, x2, C, z, z.special, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
             asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the windows
             mine = read_lane_words(lane_words_address);
@@ -1551,7 +1561,7 @@ void ssv_gather_tails(const uint64_t* __restrict__ tails, const uint32_t* __rest
 __global__ __launch_bounds__(64 * kWavesPerBlock, HAVAC_WAVES_PER_SIMD)
 void ssv_diag_kernel(const SsvRare /* read through rare_args(), never by name */,
                      const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
-                     const uint32_t* __restrict__ safe_chunks /* null with a separator mask: every chunk then tests every two steps */,
+                     const uint32_t* __restrict__ safe_chunks /* one bit per 32-row chunk: a hit test every four steps is exact there (with a separator mask: where no separator lies in the window) */,
                      const int64_t nsymbols, const uint32_t nrows_padded) {
     ssv_diag_body<false>(seq, rows, safe_chunks, nsymbols, nrows_padded);
 }
