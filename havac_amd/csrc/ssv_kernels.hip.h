@@ -22,7 +22,8 @@
 //    bottom, i.e. until the scores added after the crossing sum to -256 or less.
 //    That is why hits are looked for only once per FOUR steps wherever three
 //    consecutive model rows cannot sum below -255 (ssv_prepare_model marks those
-//    32-row chunks; elsewhere, and with separator masks, every two steps).
+//    32-row chunks; elsewhere, and where a separator pair or the matrix's edge lies in the wave's window under a
+//    separator mask, every two steps).
 //  * SKEWED PAIRS.  The two cells of a register sit on adjacent diagonals, and
 //    the high cell runs ONE ROW BEHIND the low cell: at step t the low cell is
 //    (row t, diagonal e) and the high cell (row t-1, diagonal e+1) -- the same
