@@ -176,7 +176,8 @@ struct LaunchPlan { SsvRare L{}; uint32_t nblocks = 0, largest_item_rows = 0; bo
 // masks, the per-cell trace, a forced work distribution); `variant`: -1 = this rule, 0 = always the standard kernel, 1 = the
 // resident-table one wherever it is valid (tests, A/B)
 bool pick_resident_kernel(const Tiling& t, const PlanTuning& tune, bool has_mask, bool has_trace) {
-    if (tune.variant == 0 || has_mask || has_trace || t.nrows_padded > kResidentRows) return false;
+    (void)has_mask;      // (round 5: served by ssv_resident_kernel_masked)
+    if (tune.variant == 0 || has_trace || t.nrows_padded > kResidentRows) return false;
     return tune.variant == 1 || (tune.rows_per_block < 0 && tune.tiles_per_item == -1);
 }
 int plan_launch(std::string& err, const Tiling& t, uint32_t tb, uint32_t te, int64_t col_end, uint64_t slots, const PlanTuning& tune,
@@ -742,6 +743,9 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         c->last_resident_kernel = resident_kernel;
         if (c->trace_cells)       // debugging: the same kernel body with the per-cell trace compiled in
             hipLaunchKernelGGL(ssv_diag_kernel_traced, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,
+                               d_sequence, (const uint32_t*)c->rows8, safe_chunks, (int64_t)nsymbols, t.nrows_padded);
+        else if (resident_kernel && pair_mask)
+            hipLaunchKernelGGL(ssv_resident_kernel_masked, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,
                                d_sequence, (const uint32_t*)c->rows8, safe_chunks, (int64_t)nsymbols, t.nrows_padded);
         else if (resident_kernel)    // short models: the chip's worth of workgroups, tables resident in LDS, every wave walks its run of tiles
             hipLaunchKernelGGL(ssv_resident_kernel, dim3(nblocks), dim3(64 * kWavesPerBlock), 0, stream, R,

@@ -1330,7 +1330,8 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
 //     runs, handed out by the wave's number alone): a workgroup's start, end and empty slot are paid once per launch, not
 //     once per four tiles, and nothing but the wave's own stage flush ever touches the hit counter;
 //   * the next tile's first symbols are fetched before the step behind the current tile's last chunk.
-// No separator mask, no row blocks, no trace: the host (havac_dev.hip, pick_resident_kernel) takes the standard kernel there.
+// No row blocks, no trace: the host (havac_dev.hip, pick_resident_kernel) takes the standard kernel there.  A separator mask: the
+// second instantiation, ssv_resident_kernel_masked (round 5).
 #ifdef HAVAC_WAVE_CLOCKS
 // experiments only (tools/wave_clocks.py): when each wave of the resident-table kernel started its run and left it, on the
 // chip-wide 100 MHz clock, and which SIMD it ran on
@@ -1344,8 +1345,9 @@ struct __attribute__((aligned(128))) ResidentLds {
 };
 static_assert(sizeof(uint64_t) * kWavesPerBlock * kHitStage >= kTableBytes, "the stages cover one table's worth of addresses");
 
-struct TileSymbols { uint2 w0, w1; uint32_t abort_word; };      // what a tile's prologue needs from memory
+struct TileSymbols { uint2 w0, w1; uint32_t abort_word; uint32_t separators; };      // what a tile's prologue needs from memory (separators, masked launches only: the 16 separator bits of w0, and of w1 << 16)
 
+template <bool Masked /* a separator mask is set (SsvRare::pair_mask): the second instantiation, ssv_resident_kernel_masked */>
 __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
                                                   const uint32_t* __restrict__ safe_chunks, const int64_t nsymbols,
                                                   const uint32_t nrows_padded) {
@@ -1372,7 +1374,8 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
             const lds_words_out_t out = (lds_words_out_t)(uintptr_t)(at + my_b * 32);
 #pragma unroll
             for (int a = 0; a < 4; a++) out[a] = u32x2{__builtin_amdgcn_perm(r0, r1, word_selector(a)), second};
-            if (my_b == 0) *(lds_words_out_t)(uintptr_t)(at + kOutsideCode) = u32x2{kOutsideNeutral, kOutsideNeutral};
+            // (with a separator mask the "outside" entries score -128, as in ssv_diag_body)
+            if (my_b == 0) *(lds_words_out_t)(uintptr_t)(at + kOutsideCode) = u32x2{Masked ? kOutsideReset : kOutsideNeutral, Masked ? kOutsideReset : kOutsideNeutral};
         }
     }
     __syncthreads();
@@ -1402,18 +1405,23 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
         e.edge = (uint32_t)(e.valid_lo != 0) | (uint32_t)(e.valid_hi < kTileDiags);
         return e;
     };
-    auto load_symbols = [&](const SymbolRange& e, const uint32_t lane8) -> uint2 {
+    auto load_symbols = [&](const SymbolRange& e, const uint32_t lane8, uint32_t& separators) -> uint2 {
         const uint8_t* const base = seq + (e.first >> 2);             // only dereferenced for lanes inside [0, N)
         uint2 w = make_uint2(0u, 0u);
-        if (!e.edge) w = *reinterpret_cast<const uint2*>(base + lane8);
-        else if ((int32_t)(lane8 * 4) >= e.valid_lo && (int32_t)(lane8 * 4) + 32 <= e.valid_hi) w = *reinterpret_cast<const uint2*>(base + lane8);
+        separators = 0;
+        if (!e.edge || ((int32_t)(lane8 * 4) >= e.valid_lo && (int32_t)(lane8 * 4) + 32 <= e.valid_hi)) {
+            w = *reinterpret_cast<const uint2*>(base + lane8);
+            if constexpr (Masked) separators = rare_args()->pair_mask[(e.first >> 5) + (lane8 >> 3)];
+        }
         return w;
     };
-    auto finish_symbols = [&](const SymbolRange& e, const uint2 w, const uint32_t table_base, LazySymbols& z) {
+    auto finish_symbols = [&](const SymbolRange& e, const uint2 w, const uint32_t separators, const uint32_t table_base, LazySymbols& z) {
         z.valid_lo = e.valid_lo; z.valid_hi = e.valid_hi;
         z.table_base = table_base;
-        z.separators = 0;
-        z.special = opaque_uniform(e.edge ? kFlagSpecial : 0u);
+        z.separators = Masked ? separators : 0u;
+        uint32_t special = e.edge;
+        if constexpr (Masked) special |= __any(separators != 0) ? 1u : 0u;
+        z.special = opaque_uniform(special ? kFlagSpecial : 0u);
         prepare_symbols(z, w.x, w.y);
     };
     // a tile's first diagonal and the first of its rows that can lie inside the matrix (ssv_diag_body: d0, p_lo)
@@ -1435,8 +1443,10 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
         int64_t t_d0; uint32_t t_lo;
         tile_start(t, t_d0, t_lo);
         const uint32_t lane8 = fresh_lane() * 8u;
-        L.w0 = load_symbols(symbol_range(t_d0 + t_lo), lane8);
-        L.w1 = load_symbols(symbol_range(t_d0 + t_lo + 32), lane8);
+        uint32_t s0, s1;
+        L.w0 = load_symbols(symbol_range(t_d0 + t_lo), lane8, s0);
+        L.w1 = load_symbols(symbol_range(t_d0 + t_lo + 32), lane8, s1);
+        L.separators = Masked ? (s0 | (s1 << 16)) : 0u;
         L.abort_word = 0;
         if (with_abort_word) {
             const uint32_t* const abort_flag = rare_args()->abort_flag;
@@ -1467,19 +1477,31 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
         uint32_t C[32];
         LazySymbols z;
         const uint32_t first_table = tables + (p_lo / kChunkRows) * kTableBytes;
-        finish_symbols(symbol_range(d0 + p_lo), now.w0, first_table - kTableBytes, z);
+        finish_symbols(symbol_range(d0 + p_lo), now.w0, now.separators & 0xffffu, first_table - kTableBytes, z);
+        uint32_t lower_special = z.special & kFlagSpecial;             // (masked launches: see ssv_diag_body's chunk loop)
         expand_all(C, z, std::make_integer_sequence<int, 16>{});       // -> C[16..32): the first chunk's lower half after the slide
-        finish_symbols(symbol_range(d0 + p_lo + 32), now.w1, first_table, z);
+        finish_symbols(symbol_range(d0 + p_lo + 32), now.w1, now.separators >> 16, first_table, z);
         for (uint32_t p0 = p_lo; p0 < p_hi; p0 += kChunkRows) {
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-            z.special = opaque_uniform(((safe_word >> (p0 >> 5)) & 1u) | (z.special & kFlagSpecial));            // + kFlagSafe for this chunk
+            if constexpr (Masked) {
+                // a chunk may test every four steps unless a separator pair or the matrix's edge lies in the wave's window
+                const uint32_t upper_special = z.special & kFlagSpecial;
+                uint32_t safe_bit = (safe_word >> (p0 >> 5)) & 1u;
+                if (lower_special | upper_special) safe_bit = 0;
+                lower_special = upper_special;
+                z.special = opaque_uniform(safe_bit | upper_special);
+            } else {
+                z.special = opaque_uniform(((safe_word >> (p0 >> 5)) & 1u) | (z.special & kFlagSpecial));            // + kFlagSafe for this chunk
+            }
             step_windows<false, true>(x, x2, C, z, z.special, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
             asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the windows
             if (p0 + kChunkRows < p_hi) {
                 // the next chunk's upper half (issued at the end of a chunk, consumed at the top of the next: see ssv_diag_body)
                 const SymbolRange e = symbol_range(d0 + p0 + kChunkRows + 32);
-                finish_symbols(e, load_symbols(e, fresh_lane() * 8u), tables + ((p0 >> 5) + 1u) * kTableBytes, z);
+                uint32_t separators;
+                const uint2 w = load_symbols(e, fresh_lane() * 8u, separators);
+                finish_symbols(e, w, separators, tables + ((p0 >> 5) + 1u) * kTableBytes, z);
             }
         }
         // the next tile's first loads: in flight across the step behind the last chunk and the next tile's scalar prologue
@@ -1574,7 +1596,16 @@ void ssv_diag_kernel(const SsvRare /* read through rare_args(), never by name */
 __global__ __launch_bounds__(64 * kWavesPerBlock, HAVAC_RESIDENT_WAVES)
 void ssv_resident_kernel(const SsvRare, const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
                          const uint32_t* __restrict__ safe_chunks, const int64_t nsymbols, const uint32_t nrows_padded) {
-    ssv_resident_body(seq, rows, safe_chunks, nsymbols, nrows_padded);
+    ssv_resident_body<false>(seq, rows, safe_chunks, nsymbols, nrows_padded);
+}
+// the same with a separator mask (round 5: a short model against a FASTA of several records -- the file-level API's usual case --
+// no longer falls back to the standard kernel).  An instantiation of its own: the separator word of a tile's first symbols is one
+// more word alive across the end of the tile before, which at 79 of 80 registers costs 16 B of scratch per lane -- written and read
+// once per TILE, outside the windows -- that launches without a mask do not pay.
+__global__ __launch_bounds__(64 * kWavesPerBlock, HAVAC_RESIDENT_WAVES)
+void ssv_resident_kernel_masked(const SsvRare, const uint8_t* __restrict__ seq, const uint32_t* __restrict__ rows,
+                                const uint32_t* __restrict__ safe_chunks, const int64_t nsymbols, const uint32_t nrows_padded) {
+    ssv_resident_body<true>(seq, rows, safe_chunks, nsymbols, nrows_padded);
 }
 
 // the same body with the per-cell trace compiled in (see CellRecord): a debugging aid, never launched unless a trace window is set

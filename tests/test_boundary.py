@@ -195,6 +195,12 @@ def test_ssv_kernel_resources():
     assert short["vgpr_count"] <= 80, short
     assert short["private_segment_fixed_size"] == 0 and short["sgpr_spill_count"] == 0 and short["vgpr_spill_count"] == 0, short
     assert short["group_segment_fixed_size"] <= 160 * 1024 // 6, short
+    # ... and its instantiation for launches with a separator mask (round 5: ssv_resident_kernel_masked): the same budget
+    masked = [v for k, v in kernels.items() if "26ssv_resident_kernel_masked" in k]
+    assert len(masked) == 1, sorted(kernels)
+    masked = masked[0]
+    assert masked["vgpr_count"] <= 80 and masked["private_segment_fixed_size"] == 0 and masked["vgpr_spill_count"] == 0 and masked["sgpr_spill_count"] == 0, masked
+    assert masked["group_segment_fixed_size"] <= 160 * 1024 // 6, masked
     assert any("ssv_diag_kernel_traced" in k for k in kernels) and any("ssv_gather_tails" in k for k in kernels)
     # The ordering kernels of passes that run beside each other (hit_order.hip.h) fit into the 32 VGPRs the SSV kernel leaves free
     # on a SIMD (512 - 6 x 80): a pass's ordering then runs in the shadow of the next pass's kernel instead of displacing its

@@ -55,6 +55,50 @@ def test_separator_mask_equals_independent_segments(oracle):
         c.close()
 
 
+@pytest.mark.parametrize("nrows", [31, 64, 200, 256])
+def test_short_models_with_a_separator_mask(oracle, nrows):
+    """Round 5: a short model against a sequence with separators runs the resident-table kernel's masked instantiation
+    (ssv_resident_kernel_masked; before: the standard kernel) -- and where a model is safe a chunk tests every four steps unless a
+    separator lies in the wave's window.  Separators at the start and the end of the sequence, around segment and tile (2048-diagonal)
+    borders, next to one another, in the middle of planted homologs; the run equals independent runs on the pieces.  The same through
+    the standard kernel (variant 0) and through walks of 1 and 3 tiles."""
+    from havac_amd.hw_client import HavacHwClient
+    rng = np.random.default_rng(100 + nrows)
+    n = 6 * synth.SEGMENT
+    model, cons = synth.dfam_like_model(nrows, 7 + nrows)
+    model[rng.integers(0, nrows, size=max(1, nrows // 8))] = 127     # long diagonals to cut
+    sym = synth.random_symbols(n, 5 + nrows)
+    synth.plant_homologs(sym, cons, n, every=1500, length=min(nrows, 150), sub=0.05)
+    seps = sorted(set((rng.integers(1, n // 2 - 1, size=60) * 2).tolist() + [0, 2, 2046, 2048, 2050, 4094, 4096, 12286, 12288, 12290,
+                                                                              750, 752, 2250, n - 4, n - 2]))
+    mask = np.zeros(n // 16, np.uint8)
+    for c in seps:
+        mask[c // 16] |= 1 << ((c // 2) % 8)
+    pieces, start = [], 0
+    for s_ in seps + [n]:
+        if s_ > start:
+            pieces.append((start, s_))
+        start = s_ + 2
+    want = []
+    for a, b in pieces:
+        r, cc = oracle.unpack_hits(oracle.ssv(sym[a:b], model))
+        want.append(oracle.pack_hits(r, cc + np.uint64(a)))
+    want = oracle.device_order(np.concatenate(want))
+    assert want.size > 100
+    c = HavacHwClient()
+    try:
+        for tuning in ([-1] * 9, [-1] * 8 + [0], [-1, 1, -1, -1, -1, -1, -1, -1, 1], [-1, 3, -1, -1, -1, -1, -1, -1, 1]):
+            c.setTuning(*tuning)
+            c.writeSequence(synth.pack_2bit(sym))
+            c.writeSeparatorMask(mask)
+            c.writePhmm(model)
+            c.invokeHavacSsvAsync()
+            assert c.waitForHavacSsvAsync() == 4
+            assert np.array_equal(c.getHitList(), want), tuning
+    finally:
+        c.close()
+
+
 def test_havac_boundary_mode_scores_every_pair_on_its_own(tmp_path, oracle):
     from havac_amd import havac
     from test_gpu_api import write_inputs
