@@ -1220,9 +1220,11 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
             {
+                // (bit arithmetic on 0 / 1 values, no select: a select between uniform values went through v_cndmask + v_readfirstlane here)
+                static_assert(kFlagSpecial == 2u && kFlagSafe == 1u, "the flags' positions are used below");
                 const uint32_t upper_special = z.special & kFlagSpecial;
-                uint32_t safe_bit = (safe_now >> ((p0 >> 5) & 31u)) & 1u;
-                if (fresh_uniform(has_mask) && (lower_special | upper_special)) safe_bit = 0;
+                const uint32_t blocked = fresh_uniform(has_mask) & ((lower_special | upper_special) >> 1);      // 1: a separator or the edge in the window, under a mask
+                const uint32_t safe_bit = (safe_now >> ((p0 >> 5) & 31u)) & (blocked ^ 1u);
                 lower_special = upper_special;                    // (what it is once this chunk's symbols have slid down)
                 z.special = opaque_uniform(safe_bit | upper_special);     // + kFlagSafe for this chunk
             }
@@ -1487,8 +1489,8 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
             if constexpr (Masked) {
                 // a chunk may test every four steps unless a separator pair or the matrix's edge lies in the wave's window
                 const uint32_t upper_special = z.special & kFlagSpecial;
-                uint32_t safe_bit = (safe_word >> (p0 >> 5)) & 1u;
-                if (lower_special | upper_special) safe_bit = 0;
+                const uint32_t blocked = (lower_special | upper_special) >> 1;      // (bit arithmetic, no select: see ssv_diag_body)
+                const uint32_t safe_bit = (safe_word >> (p0 >> 5)) & (blocked ^ 1u);
                 lower_special = upper_special;
                 z.special = opaque_uniform(safe_bit | upper_special);
             } else {
