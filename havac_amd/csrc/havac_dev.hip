@@ -318,7 +318,7 @@ inline size_t handoff_slots(const SsvRare& L) {
 struct havac_ssv_ctx {
     int device = 0;
     uint32_t* rows8 = nullptr; size_t rows8_rows = 0;   // padded copy of the model
-    uint32_t* chunk_flags = nullptr; size_t chunk_flag_words = 0;   // one bit per 32-row chunk: hit test every four steps allowed
+    uint32_t* chunk_flags = nullptr; size_t chunk_flag_words = 0;   // one byte per 32-row chunk, bit Q: window Q may test for hits at its end only
     // work distribution of the persistent kernel (ssv_kernels.hip.h, SsvLaunch)
     // the words a pass's kernels count in, cleared by ssv_prepare_model in front of every pass: [0, 144) the ticket counters of cut
     // tiles and the fault word, [144, 160) the ordering's OrderState (hit_order.hip.h)
@@ -625,7 +625,7 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         HIP_TRY(c->err, hipMalloc(&c->rows8, (size_t)model_words * sizeof(uint32_t)));
         c->rows8_rows = model_words;
     }
-    const uint32_t flag_words = (t.nrows_padded / kChunkRows + 1 + 31) / 32 + 1;   // + 1: the kernel loads one word ahead
+    const uint32_t flag_words = (t.nrows_padded / kChunkRows + 1 + 3) / 4 + 2;     // a byte per chunk; + 2: the kernels load a word ahead
     if (c->chunk_flag_words < flag_words) {
         if (c->chunk_flags) (void)hipFree(c->chunk_flags);
         c->chunk_flags = nullptr; c->chunk_flag_words = 0;
@@ -723,7 +723,7 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
     // edge of the matrix lies in the wave's window, see ssv_diag_body.)
     {
         const uint32_t nflagwords = flag_words;
-        const uint32_t threads = std::max(std::max(model_words, nflagwords * 32u), kControlWords);
+        const uint32_t threads = std::max(std::max(model_words, nflagwords * 4u), kControlWords);
         hipLaunchKernelGGL(ssv_prepare_model, dim3((threads + 255) / 256), dim3(256), 0, stream, d_phmm, nrows, c->rows8, model_words,
                            t.nrows_padded, c->chunk_flags, nflagwords, c->d_count, c->control, kControlWords, c->block_flags, (uint32_t)handoff_words);
     }

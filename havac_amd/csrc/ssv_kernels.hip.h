@@ -151,12 +151,13 @@ __device__ __forceinline__ uint32_t padded_model_row(const uint32_t* __restrict_
     return (i >= 1 && i <= nrows) ? phmm_rows[i - 1] : kPadRow;
 }
 
-// Which 32-step chunks may test for hits every FOUR steps instead of every two.  A crossed cell is recognised by its
+// Which four-step windows may test for hits at their end only instead of in the middle too.  A crossed cell is recognised by its
 // low byte (0x7fff), and it loses that mark only by saturating at the bottom, i.e. when the scores added after the
-// crossing sum to -256 or less.  Inside a window of four steps at most three steps follow a crossing, so a chunk is
-// safe when no three consecutive rows it touches (rows 32c-1 .. 32c+31: the high cells run one row behind) can sum
-// below -255 whatever the symbols are.  One bit per chunk; the same kernel writes the padded model.
-// ONE launch prepares a pass: thread i writes word i of the padded model, thread c the flag of chunk c (from the model
+// crossing sum to -256 or less.  Inside a window of four steps at most three steps follow a crossing, so a window is
+// safe when the three rows that can follow a crossing in it (the high cells run one row behind) cannot sum below -255 whatever the
+// symbols are.  One bit per window = one byte per 32-row chunk (round 5; before: one bit per chunk -- a model with one strongly
+// negative stretch per chunk tested every two steps everywhere, +8.5 % on C2); the same kernel writes the padded model.
+// ONE launch prepares a pass: thread i writes word i of the padded model, thread c the flags of chunk c (from the model
 // itself, not from the padded copy: the two halves do not depend on each other), thread 0 clears the hit counter.  As
 // three dispatches (memset, pad, flags) in front of every SSV kernel the preparation cost ~30 us of dispatch gaps per
 // pass -- 1.5 % of a C2 step -- for 10 us of work.
@@ -174,29 +175,32 @@ __global__ void ssv_prepare_model(const int8_t* __restrict__ phmm, uint32_t nrow
     for (uint32_t k = i; k < nhandoff; k += gridDim.x * blockDim.x) handoff[k] = 0u;
     if (i < nwords) rows[i] = padded_model_row(phmm_rows, nrows, i);
     if (nflagwords == 0) return;
-    // one thread per chunk, 64 chunks = two flag words per wave
+    // one thread per chunk: a byte, bit Q = window Q (steps 4Q .. 4Q+3 of the chunk) may look for hits at its end only
     const uint32_t chunk = i;
     const uint32_t p0 = chunk * kChunkRows;
-    bool safe = false;
-    if (chunk / 32 < nflagwords && p0 < nrows_padded + kChunkRows) {
-        // rows p0-1 .. p0+31 are padded rows p0 .. p0+32: the lowest score of each (at most 0; 0 beyond the model) ...
-        int lowest[kChunkRows + 1];
+    if (chunk / 4 >= nflagwords) return;
+    uint32_t bits = 0;
+    if (p0 < nrows_padded + kChunkRows) {
+        // model rows p0 .. p0+34 are padded rows p0+1 .. p0+35: the lowest score of each (at most 0; 0 beyond the model) ...
+        int lowest[kChunkRows + 3];
 #pragma unroll
-        for (int k = 0; k <= kChunkRows; k++) {
-            const uint32_t r = padded_model_row(phmm_rows, nrows, p0 + k);
+        for (int k = 0; k < kChunkRows + 3; k++) {
+            const uint32_t r = padded_model_row(phmm_rows, nrows, p0 + 1 + k);
             int m = 0;
 #pragma unroll
             for (int a = 0; a < 4; a++) m = min(m, (int)(int8_t)(r >> (8 * a)));
             lowest[k] = m;
         }
-        // ... and every run of three of them
-        safe = true;
+        // ... and the two runs of three that can follow a crossing inside window Q: a high cell that crosses at the window's first
+        // step (on row 4Q - 1) adds rows 4Q, 4Q+1, 4Q+2 before the test, a low cell (on row 4Q) rows 4Q+1, 4Q+2, 4Q+3; a crossing at
+        // a later step adds a suffix of one of them, which sums to no less (no `lowest` is positive)
 #pragma unroll
-        for (int k = 0; k + 2 <= kChunkRows; k++) safe = safe && (lowest[k] + lowest[k + 1] + lowest[k + 2] >= -255);
+        for (int q = 0; q < kChunkRows / kWindowSteps; q++) {
+            const int high = lowest[4 * q] + lowest[4 * q + 1] + lowest[4 * q + 2], low = lowest[4 * q + 1] + lowest[4 * q + 2] + lowest[4 * q + 3];
+            if (high >= -255 && low >= -255) bits |= 1u << q;
+        }
     }
-    const unsigned long long bits = __ballot(safe);
-    const uint32_t lane = threadIdx.x & 63, word = chunk / 32;
-    if (word < nflagwords && (lane & 31) == 0) flags[word] = (uint32_t)(bits >> (lane & 32));
+    reinterpret_cast<uint8_t*>(flags)[chunk] = (uint8_t)bits;
 }
 
 // ---------------------------------------------------------------------------
@@ -520,14 +524,15 @@ __device__ __forceinline__ LaneWords read_lane_words(uint32_t lds_address) {
 // the 8 bytes loaded for this chunk and are expanded entry by entry: window Q (steps 4Q..4Q+3) uses entries 2Q..2Q+16
 // only, so 17 of the 32 addresses (plus the four prepared words) are alive at a time -- the registers that let both
 // score sets stay alive at six waves per SIMD.
-constexpr uint32_t kFlagSafe = 1u, kFlagSpecial = 2u;
+constexpr uint32_t kFlagSpecial = 2u;
+constexpr int kFlagSafeShift = 8;       // bits 8 .. 15 of the flag word: window Q of the chunk may look for hits at its end only (ssv_prepare_model)
 struct LazySymbols {
     uint32_t even[2], odd[2];   // per packed word (pairs 16..23, 24..31): code*8 of its even / odd pairs, one per byte
     uint32_t separators;        // bit K: pair 16+K is a separator pair (boundary mode); 0 otherwise
     uint32_t table_base;
     uint32_t special;           // wave-uniform flag word (a 32-bit SGPR, not a lane mask).  kFlagSpecial: some position of the wave lies outside [0, N), or a
-                                // separator is present; kFlagSafe (set by the chunk loop for the chunk it enters): the chunk may test for hits every four
-                                // steps.  ONE word for both: every window entry's asm takes it as an "s" operand, and with two such words alive through
+                                // separator is present; bits kFlagSafeShift + Q (set by the chunk loop for the chunk it enters): window Q may test for hits at
+                                // its end only.  ONE word for both: every window entry's asm takes it as an "s" operand, and with two such words alive through
                                 // the windows hipcc's allocator once moved one into a VGPR ("illegal VGPR to SGPR copy")
     int32_t valid_lo, valid_hi; // wave-uniform: positions relative to the wave's first that lie inside [0, N): [valid_lo, valid_hi)
 };
@@ -845,7 +850,7 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
                 trace_step<true>(win, h * H + i, step0 + 4 * Q + 1, wave_diag0, mid[i], m[i].y, nxt[h * H + i], C[2 * Q + h * H + i], table_base);
         }
     }
-    if (!(fresh_uniform(safe) & kFlagSafe)) {
+    if (!(fresh_uniform(safe) & (1u << (kFlagSafeShift + Q)))) {
         uint32_t any = 0;
 #pragma unroll
         for (int i = 0; i < kRegs; i++) any |= nxt[i];
@@ -886,7 +891,7 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
 #pragma unroll
     for (int i = 0; i < kRegs; i++) any |= nxt[i];
     if (const unsigned long long lanes = __ballot((any & kCrossedBits) != 0); __builtin_expect(lanes != 0, 0))
-        window_slow<Resident, Q, kWindowSteps>(cur, nxt, C, lanes, (int)(2u - 2u * (safe & kFlagSafe)), sink, staged, step0, wave_diag0, regs);
+        window_slow<Resident, Q, kWindowSteps>(cur, nxt, C, lanes, (int)(2u - 2u * ((safe >> (kFlagSafeShift + Q)) & 1u)), sink, staged, step0, wave_diag0, regs);
 }
 
 // ONE step with the tables of step pair 0 (the step behind the model's last chunk: the high cells run one row behind
@@ -1203,12 +1208,12 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
         // With a separator mask (round 5; before: never) a chunk may, too, unless a separator pair or the matrix's edge lies in the wave's
         // window of 64 symbols: the "outside" entry then scores -128, two of them take a crossed cell's mark away inside a window.
         // `lower_special`: the flag of the symbols that have slid into the window's lower half (z.special holds the upper half's).
-        uint32_t safe_now = safe_chunks[p_begin >> 10];
-        uint32_t safe_next = safe_chunks[(p_begin >> 10) + 1];
+        uint32_t safe_now = safe_chunks[p_begin >> 7];             // (a byte per chunk: a word holds 128 rows' worth)
+        uint32_t safe_next = safe_chunks[(p_begin >> 7) + 1];
         for (uint32_t p0 = p_begin; p0 < p_end; p0 += kChunkRows) {
-            if ((p0 & 1023) == 0 && p0 != p_begin) {
+            if ((p0 & 127) == 0 && p0 != p_begin) {
                 safe_now = safe_next;
-                safe_next = safe_chunks[(p0 >> 10) + 1];
+                safe_next = safe_chunks[(p0 >> 7) + 1];
             }
             // abort: a device word, read past the caches every 2048 rows inside an item (and between items, below)
             if (((p0 & 2047) == 0) && p0 != p_begin) {
@@ -1221,12 +1226,12 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
             {
                 // (bit arithmetic on 0 / 1 values, no select: a select between uniform values went through v_cndmask + v_readfirstlane here)
-                static_assert(kFlagSpecial == 2u && kFlagSafe == 1u, "the flags' positions are used below");
+                static_assert(kFlagSpecial == 2u, "the flag's position is used below");
                 const uint32_t upper_special = z.special & kFlagSpecial;
                 const uint32_t blocked = fresh_uniform(has_mask) & ((lower_special | upper_special) >> 1);      // 1: a separator or the edge in the window, under a mask
-                const uint32_t safe_bit = (safe_now >> ((p0 >> 5) & 31u)) & (blocked ^ 1u);
+                const uint32_t safe_bits = ((safe_now >> ((p0 >> 2) & 24u)) & 0xffu) & (blocked - 1u);         // the chunk's byte, or nothing
                 lower_special = upper_special;                    // (what it is once this chunk's symbols have slid down)
-                z.special = opaque_uniform(safe_bit | upper_special);     // + kFlagSafe for this chunk
+                z.special = opaque_uniform((safe_bits << kFlagSafeShift) | upper_special);     // + the windows' flags for this chunk
             }
             step_windows<Trace, false>(x, x2, C, z, z.special, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
             asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the windows
@@ -1396,7 +1401,8 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
         if (tile > ntiles) tile = ntiles;
         if (tile_end > ntiles) tile_end = ntiles;
     }
-    const uint32_t safe_word = safe_chunks[0];        // a model of up to 1024 rows lies inside the first flag word
+    // (a byte per chunk: a model of up to 256 rows lies inside the first two flag words)
+    const uint64_t safe_words = (uint64_t)safe_chunks[0] | ((uint64_t)safe_chunks[1] << 32);
 
     struct SymbolRange { int64_t first; int32_t valid_lo, valid_hi; uint32_t edge; };
     auto symbol_range = [&](int64_t first) -> SymbolRange {          // the wave's 2048 positions from `first` on (see ssv_diag_body)
@@ -1490,11 +1496,11 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
                 // a chunk may test every four steps unless a separator pair or the matrix's edge lies in the wave's window
                 const uint32_t upper_special = z.special & kFlagSpecial;
                 const uint32_t blocked = (lower_special | upper_special) >> 1;      // (bit arithmetic, no select: see ssv_diag_body)
-                const uint32_t safe_bit = (safe_word >> (p0 >> 5)) & (blocked ^ 1u);
+                const uint32_t safe_bits = ((uint32_t)(safe_words >> (p0 >> 2)) & 0xffu) & (blocked - 1u);
                 lower_special = upper_special;
-                z.special = opaque_uniform(safe_bit | upper_special);
+                z.special = opaque_uniform((safe_bits << kFlagSafeShift) | upper_special);
             } else {
-                z.special = opaque_uniform(((safe_word >> (p0 >> 5)) & 1u) | (z.special & kFlagSpecial));            // + kFlagSafe for this chunk
+                z.special = opaque_uniform((((uint32_t)(safe_words >> (p0 >> 2)) & 0xffu) << kFlagSafeShift) | (z.special & kFlagSpecial));      // + the windows' flags for this chunk
             }
             step_windows<false, true>(x, x2, C, z, z.special, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
             asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the windows
