@@ -20,9 +20,10 @@
 //    multiple of 256, so a crossed cell is recognisable afterwards by a non-zero
 //    low byte (0x7fff), and it stays recognisable until it saturates at the
 //    bottom, i.e. until the scores added after the crossing sum to -256 or less.
-//    That is why hits are looked for only once per FOUR steps wherever three
-//    consecutive model rows cannot sum below -255 (ssv_prepare_model marks those
-//    32-row chunks; elsewhere, and where a separator pair or the matrix's edge lies in the wave's window under a
+//    That is why hits are looked for only once per FOUR steps wherever the three
+//    model rows that can follow a crossing cannot sum below -255 (ssv_prepare_model
+//    marks those four-step windows, a byte per 32-row chunk; elsewhere, and where a
+//    separator pair or the matrix's edge lies in the wave's window under a
 //    separator mask, every two steps).
 //  * SKEWED PAIRS.  The two cells of a register sit on adjacent diagonals, and
 //    the high cell runs ONE ROW BEHIND the low cell: at step t the low cell is
