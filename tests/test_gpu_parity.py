@@ -82,6 +82,38 @@ def test_extreme_models(client, oracle, seed):
     assert got.size == want.size and np.array_equal(got, want), first_difference(got, want, oracle)
 
 
+@pytest.mark.parametrize("nrows", [150, 700])
+def test_marks_that_would_vanish_inside_a_window(client, oracle, nrows):
+    """Round 5: whether a four-step window may look for hits at its end only is decided per WINDOW (a byte per 32-row chunk,
+    ssv_prepare_model).  A mild model -- every window safe -- with, at every residue of the row index modulo 32 in turn, a crossing
+    forced by rows of +127 and then two or three rows that take the mark away again within the window if nobody looks in its middle
+    (-128 or -90 for every symbol): the windows those rows lie in must test twice, their neighbours need not.  The resident-table
+    kernel (150 rows) and the standard one (700 rows, and 150 rows forced), sequences with and without planted homologs."""
+    rng = np.random.default_rng(nrows)
+    model = rng.integers(-40, -9, size=(nrows, 4)).astype(np.int8)
+    cons = rng.integers(0, 4, size=nrows)
+    model[np.arange(nrows), cons] = rng.integers(30, 60, size=nrows).astype(np.int8)
+    # the bait: from row r on, three rows of +127 for every symbol (a sure crossing on rows r+1 or r+2 wherever the score is above
+    # 2), then `k` rows that score `low` for every symbol; r walks through every residue modulo 32 and both cells' phases
+    r, step = 3, 37
+    while r + 6 < nrows:
+        k, low = int(rng.integers(2, 4)), int(rng.choice([-128, -90]))
+        model[r:r + 3] = 127
+        model[r + 3:r + 3 + k] = low
+        r += step
+    n = 3 * synth.SEGMENT
+    sym = synth.random_symbols(n, seed=nrows + 1)
+    synth.plant_homologs(sym, cons.astype(np.uint8), n, every=2500, length=min(nrows, 300), sub=0.02, seed=nrows + 2)
+    want = oracle.ssv_mt(sym, model)
+    assert want.size > 10_000
+    client.setHitCapacity(want.size + 64)
+    for variant in ([-1] * 9, [-1] * 8 + [0]):
+        client.setTuning(*variant)
+        got = run(client, synth.pack_2bit(sym), model)
+        assert got.size == want.size and np.array_equal(got, want), (variant, first_difference(got, want, oracle))
+    client.setTuning(*([-1] * 9))
+
+
 def test_rows_exactly_at_chunk_multiples(client, oracle):
     """Model lengths 32k-1, 32k, 32k+1 around the kernel's 32-row chunk: the last row belongs to the lagging cells."""
     rng = np.random.default_rng(77)
