@@ -732,6 +732,7 @@ extern "C" int havac_ssv_enqueue(havac_ssv_ctx* c, const uint8_t* d_sequence, ui
         SsvRare& R = L;
         R.hits = d_hits; R.hit_count = c->d_count; R.hit_capacity = hit_capacity;
         R.col_begin = (int64_t)col_begin; R.col_span = col_end - col_begin;
+        R.half_tail = (resident_kernel && t.nrows_padded - nrows >= (uint32_t)kChunkRows / 2) ? 1u : 0u;
         R.abort_flag = d_abort_flag; R.pair_mask = pair_mask; R.tickets = c->control + kControlTickets; R.block_flags = c->block_flags; R.block_state = c->block_state;
         R.fault = c->control + kControlFault; R.row_bits = row_bits;
         R.tails = use_tails ? c->tails : nullptr; R.tail_counts = use_tails ? c->tail_counts : nullptr;

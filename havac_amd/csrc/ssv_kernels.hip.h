@@ -383,6 +383,7 @@ struct SsvRare {
     // ssv_resident_kernel: the launch's waves come in walk_rounds rounds of walk_slots waves (the last round: as many as it takes);
     // wave i of round r walks walk_len[r] adjacent tiles from tile walk_base[r] + i * walk_len[r] on (clipped to the launch's tiles)
     uint32_t walk_slots, walk_rounds, walk_len[kMaxWalkRounds], walk_base[kMaxWalkRounds];
+    uint32_t half_tail;            // ssv_resident_kernel: 1 = the model's rows end in the first half of the last chunk, whose second half is not run
     uint32_t split_units;          // of every partition's units the LAST split_units are cut by rows (0: no tile of this launch is cut)
     uint32_t nrow_blocks;          // row blocks of a cut tile
     uint32_t ncuts, uniform_rows;  // block b < ncuts is rows [row_cut[b], row_cut[b+1]); from block ncuts on the blocks are uniform_rows rows each
@@ -895,9 +896,11 @@ __device__ __forceinline__ void step_window(const uint32_t (&cur)[kRegs], uint32
         window_slow<Resident, Q, kWindowSteps>(cur, nxt, C, lanes, (int)(2u - 2u * ((safe >> (kFlagSafeShift + Q)) & 1u)), sink, staged, step0, wave_diag0, regs);
 }
 
-// ONE step with the tables of step pair 0 (the step behind the model's last chunk: the high cells run one row behind
-// and still owe the last row; the low cells add a padding row, which scores 0).
-template <bool Trace, bool Resident, int... I>
+// ONE step with the tables of step pair 2 * PQ (PQ = 0: the step behind the model's last chunk, after the window has slid: the high
+// cells run one row behind and still owe the last row; the low cells add a padding row, which scores 0.  PQ = 4, round 5: the same
+// step in the MIDDLE of the last chunk, where a short model's rows end in the chunk's first half -- `step0` is then the chunk's
+// first step, as for a window).
+template <bool Trace, bool Resident, int PQ, int... I>
 __device__ __forceinline__ void step_last(const uint32_t (&cur)[kRegs], uint32_t (&nxt)[kRegs], const uint32_t (&C)[32],
                                           const HitSink& sink, uint32_t& staged, uint32_t step0, int64_t wave_diag0,
                                           uint32_t table_base, std::integer_sequence<int, I...> regs) {
@@ -909,33 +912,36 @@ __device__ __forceinline__ void step_last(const uint32_t (&cur)[kRegs], uint32_t
         u32x2 m[H];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < H; i++) m[i] = match_words<0>(C[h * H + i], slid_offset<Resident>(h * H + i));
+        for (int i = 0; i < H; i++) m[i] = match_words<2 * PQ>(C[2 * PQ + h * H + i], slid_offset<Resident>(2 * PQ + h * H + i));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < H; i++) asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(nxt[h * H + i]) : "v"(cur[h * H + i]), "v"(m[i].x));
         if constexpr (Trace) {
 #pragma unroll
             for (int i = 0; i < H; i++)
-                trace_step<false>(win, h * H + i, step0, wave_diag0, cur[h * H + i], m[i].x, nxt[h * H + i], C[h * H + i], table_base);
+                trace_step<false>(win, h * H + i, step0 + kWindowSteps * PQ, wave_diag0, cur[h * H + i], m[i].x, nxt[h * H + i], C[2 * PQ + h * H + i], table_base);
         }
     }
     uint32_t any = 0;
 #pragma unroll
     for (int i = 0; i < kRegs; i++) any |= nxt[i];
     if (const unsigned long long lanes = __ballot((any & kCrossedBits) != 0); __builtin_expect(lanes != 0, 0))
-        window_slow<Resident, 0, 1>(cur, nxt, C, lanes, 0, sink, staged, step0, wave_diag0, regs);
+        window_slow<Resident, PQ, 1>(cur, nxt, C, lanes, 0, sink, staged, step0, wave_diag0, regs);
 }
 
-// windows 0 .. N-1 of a chunk; the scores are in `a` on entry and, N being even, in `a` again on exit
+// windows Q... of a chunk, in order (all eight, or -- round 5, the resident-table kernel -- the first four and the last four as two
+// calls, the second of which is not made where a short model ends in the chunk's first half); an even number of them starting at an
+// even one: the scores are in `a` on entry and in `a` again on exit
 template <bool Trace, bool Resident, int... Q>
 __device__ __forceinline__ void step_windows(uint32_t (&a)[kRegs], uint32_t (&b)[kRegs], uint32_t (&C)[32],
                                              const LazySymbols& z, uint32_t safe, const HitSink& sink, uint32_t& staged,
                                              uint32_t step0, int64_t wave_diag0, std::integer_sequence<int, Q...>) {
-    static_assert(sizeof...(Q) % 2 == 0 && sizeof...(Q) * kWindowSteps == kChunkRows, "a whole chunk, an even number of windows");
+    static_assert(sizeof...(Q) % 2 == 0 && sizeof...(Q) * kWindowSteps <= kChunkRows, "an even number of windows");
+    constexpr int last = std::max({Q...});
     ((expand_for_window<Q>(C, z),
       (Q % 2 == 0 ? step_window<Trace, Resident, Q>(a, b, C, safe, sink, staged, step0, wave_diag0, z.table_base, std::make_integer_sequence<int, kRegs>{})
                   : step_window<Trace, Resident, Q>(b, a, C, safe, sink, staged, step0, wave_diag0, z.table_base, std::make_integer_sequence<int, kRegs>{}))), ...);
-    expand_entry<15>(C, z);      // entry 31: entry 15 of the next chunk
+    if constexpr (last == kChunkRows / kWindowSteps - 1) expand_entry<15>(C, z);      // entry 31: entry 15 of the next chunk
 }
 
 // ---- block tails ----------------------------------------------------------------------------------------------------
@@ -1246,7 +1252,7 @@ __device__ __forceinline__ void ssv_diag_body(const uint8_t* __restrict__ seq, c
             build_tables(next_rows);                               // fetched for p_end by the last chunk
 #pragma unroll
             for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-            step_last<Trace, false>(x, x2, C, sink, staged, p_end, d0, table_base, std::make_integer_sequence<int, kRegs>{});
+            step_last<Trace, false, 0>(x, x2, C, sink, staged, p_end, d0, table_base, std::make_integer_sequence<int, kRegs>{});
         } else if (p_end < p_hi) {
             // the tile goes on in the next row block: hand the scores over (release: the stores, then the count)
             const rare_args_t rare = rare_args();
@@ -1402,6 +1408,9 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
         if (tile > ntiles) tile = ntiles;
         if (tile_end > ntiles) tile_end = ntiles;
     }
+    // Round 5: where the model's rows end in the first half of its last chunk (rows mod 32 in 1 .. 16) the chunk's second half -- sixteen
+    // steps of padding rows that change no score -- is not run: a 40-row model costs 48 steps, not 64
+    const uint32_t half_tail = opaque_uniform(rare_args()->half_tail);
     // (a byte per chunk: a model of up to 256 rows lies inside the first two flag words)
     const uint64_t safe_words = (uint64_t)safe_chunks[0] | ((uint64_t)safe_chunks[1] << 32);
 
@@ -1503,7 +1512,9 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
             } else {
                 z.special = opaque_uniform((((uint32_t)(safe_words >> (p0 >> 2)) & 0xffu) << kFlagSafeShift) | (z.special & kFlagSpecial));      // + the windows' flags for this chunk
             }
-            step_windows<false, true>(x, x2, C, z, z.special, sink, staged, p0, d0, std::make_integer_sequence<int, kChunkRows / kWindowSteps>{});
+            step_windows<false, true>(x, x2, C, z, z.special, sink, staged, p0, d0, std::integer_sequence<int, 0, 1, 2, 3>{});
+            if (!(fresh_uniform(half_tail) && p0 + kChunkRows == nrows_padded))      // (not where the model's rows end in this chunk's first half)
+                step_windows<false, true>(x, x2, C, z, z.special, sink, staged, p0, d0, std::integer_sequence<int, 4, 5, 6, 7>{});
             asm volatile("" ::: "memory");                        // keeps hipcc from hoisting the loads above the windows
             if (p0 + kChunkRows < p_hi) {
                 // the next chunk's upper half (issued at the end of a chunk, consumed at the top of the next: see ssv_diag_body)
@@ -1517,9 +1528,15 @@ __device__ __forceinline__ void ssv_resident_body(const uint8_t* __restrict__ se
         // (issued here, not inside the chunk loop: nothing of them is alive through the windows)
         if (more) issue_tile_loads(tile + 1, ahead, false);
         if (p_hi == nrows_padded) {
+            if (fresh_uniform(half_tail)) {
+                // the step behind the model's last row lies in the middle of the last chunk: its pair 8, no slide
+                expand_entry<7>(C, z);      // (entry 23: what window 4 would have expanded)
+                step_last<false, true, 4>(x, x2, C, sink, staged, p_hi - kChunkRows, d0, 0u, std::make_integer_sequence<int, kRegs>{});
+            } else {
 #pragma unroll
-            for (int k = 0; k < 16; k++) C[k] = C[k + 16];
-            step_last<false, true>(x, x2, C, sink, staged, p_hi, d0, 0u, std::make_integer_sequence<int, kRegs>{});
+                for (int k = 0; k < 16; k++) C[k] = C[k + 16];
+                step_last<false, true, 0>(x, x2, C, sink, staged, p_hi, d0, 0u, std::make_integer_sequence<int, kRegs>{});
+            }
         }
         return true;
     };

@@ -254,6 +254,8 @@ def test_ssv_kernel_instruction_mix(tmp_path):
     # upset as the standard kernel's: a tile loop written without the lambda around a tile's body moved 130-160 registers per
     # chunk and spilled, at 30.5 instead of 39.8 TCUPS on 32 rows)
     short = asm_chunk.chunk_mix(isa, "_ZN5havac19ssv_resident_kernel")
-    assert short["chunk"]["v_pk_add_i16"] == 512 and short["windows"]["ds_read_b64"] == 256, dict(short["chunk"])
+    # (its chunk is two calls of four windows since round 5 -- the second is skipped where a short model ends in the chunk's first
+    # half -- so the reads are counted over the whole chunk, not over the region between the first and the last window)
+    assert short["chunk"]["v_pk_add_i16"] == 512 and short["chunk"]["ds_read_b64"] == 256, dict(short["chunk"])
     assert asm_chunk.total(short["chunk"], ("v_",)) <= 625 and asm_chunk.total(short["chunk"], ("scratch_",)) == 0, dict(short["chunk"])
     assert short["chunk"].get("v_perm_b32", 0) == 0 and asm_chunk.total(short["chunk"], ("ds_write",)) == 0, dict(short["chunk"])

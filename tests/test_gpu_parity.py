@@ -114,6 +114,27 @@ def test_marks_that_would_vanish_inside_a_window(client, oracle, nrows):
     client.setTuning(*([-1] * 9))
 
 
+@pytest.mark.parametrize("nrows", [1, 7, 16, 17, 33, 40, 48, 49, 80, 100, 144, 145, 240])
+def test_models_that_end_in_the_first_half_of_their_last_chunk(client, oracle, nrows):
+    """Round 5: the resident-table kernel does not run the second half of a model's last chunk where the model's rows end in the
+    first (rows mod 32 in 1 .. 16: sixteen steps of padding rows that change no score; the step the lagging cells still owe is
+    taken in the chunk's middle).  Heights on both sides of the rule, the model's last rows deciding hits, every kernel."""
+    rng = np.random.default_rng(5000 + nrows)
+    model = rng.integers(-40, 60, size=(nrows, 4)).astype(np.int8)
+    model[-1] = 127                                       # the very last row decides hits: the lagging cells' last step matters
+    if nrows > 2:
+        model[-2] = rng.integers(60, 128, size=4).astype(np.int8)
+    sym = synth.random_symbols(2 * synth.SEGMENT, seed=6000 + nrows)
+    want = oracle.ssv_mt(sym, model)
+    assert want.size > 100 or nrows < 3                   # (one or two rows cannot reach 256)
+    client.setHitCapacity(want.size + 64)
+    for variant in ([-1] * 9, [-1] * 8 + [0], [-1, 2, -1, -1, -1, -1, -1, -1, 1]):
+        client.setTuning(*variant)
+        got = run(client, synth.pack_2bit(sym), model)
+        assert got.size == want.size and np.array_equal(got, want), (variant, first_difference(got, want, oracle))
+    client.setTuning(*([-1] * 9))
+
+
 def test_rows_exactly_at_chunk_multiples(client, oracle):
     """Model lengths 32k-1, 32k, 32k+1 around the kernel's 32-row chunk: the last row belongs to the lagging cells."""
     rng = np.random.default_rng(77)
