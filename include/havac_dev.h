@@ -321,8 +321,9 @@ int havac_ssv_set_split_tuning(havac_ssv_ctx *ctx, int parts_log2, int split_rou
 /* Which SSV kernel the next passes run.  -1 (the default): the library decides -- models of up to 256 (padded) rows take
  * ssv_resident_kernel: a tile of such a model is one to eight 32-row chunks and, handed out tile by tile, mostly prologue, so
  * ALL the model's match-word tables are built once per workgroup and kept in LDS, every wave walks a run of adjacent tiles, and
- * the runs are handed out in tapering rounds (havac_launch_plan: walk_len / walk_base); everything else, and every pass with a
- * separator mask, a cell trace or a forced work distribution (havac_ssv_set_tuning), takes the standard kernel, ssv_diag_kernel.
+ * the runs are handed out in tapering rounds (havac_launch_plan: walk_len / walk_base); with a separator mask its second
+ * instantiation, ssv_resident_kernel_masked (round 5); everything else, and every pass with a cell trace or a forced work
+ * distribution (havac_ssv_set_tuning), takes the standard kernel, ssv_diag_kernel.
  * 0: always the standard kernel; 1: the resident-table kernel wherever it is valid (A/B, tests; with tiles_per_item = G >= 1:
  * runs of G tiles throughout).  The records are the same either way.  The reference's array runs at the same efficiency whatever
  * the model's height (README.md:4; device/HavacHls.cpp:220-319): this is what keeps short models near that.
